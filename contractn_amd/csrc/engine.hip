@@ -1,0 +1,845 @@
+// engine.hip - gfx950 kernels + executor + C ABI of the contraction engine.
+//
+// Replaces the stabilised pairwise loop of the reference
+// (contractn/einsum.py:326-393) and stabilize() (einsum.py:89-107):
+//
+//   * every pairwise step C[b,m,n] = sum_k A[b,m,k] * B[b,k,n] runs as ONE kernel whose
+//     loads/stores go through gather-offset tables (transpose/reshape fused into
+//     the load; reference einsum.py:371-377 does tensordot + transpose copies);
+//   * a label kept while shared (copy tensor / hyperedge, reference ctn.py:154-165)
+//     is a batch index of that kernel - no identity tensor is ever materialised;
+//   * stabilize() is fused: the epilogue divides by the producers' rescale
+//     factors (applied lazily: (A/sA)(B/sB) == (A B)/sA/sB), stores the
+//     un-normalised tile and emits one partial sum of |C| per workgroup.  The
+//     consumer (or the finishing pass) reduces <= 64 partials with one wave in a
+//     fixed order, so results are bit-reproducible run to run (no float atomics).
+//
+// Written for CDNA4 only: 64-lane waves, v_mfma_f32_32x32x2_f32, 160 KiB LDS/CU.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "plan.h"
+
+namespace ctn {
+
+// ---------------------------------------------------------------------------
+// kernel arguments
+// ---------------------------------------------------------------------------
+struct StepArgs {
+  const int32_t *obA, *obB, *obC, *omA, *omC, *onB, *onC, *okA, *okB;
+  void* const* ptrs;    // [R][n_tensors] base pointer of every tensor of every replica
+  const double* partA;  // [R][64] abs-sum partials of A's producer step, nullptr for inputs
+  const double* partB;
+  double* partC;        // [R][partC_stride] where this step's partials go
+  double numelA, numelB;
+  double min_norm;
+  int32_t Bt, M, N, K;
+  int32_t idA, idB, idC, n_tensors;
+  int32_t PA, PB;
+  int32_t partC_stride;
+  int32_t tiles_m, tiles_n;
+  int32_t blocks_per_replica;
+  int32_t R;
+};
+
+struct FinalArgs {
+  void* const* ptrs;
+  const double* partials;   // [n_steps][R][64]
+  const int32_t* stepP;     // [n_steps] partial count of each step
+  const double* stepNumel;  // [n_steps] numel of each step's output
+  double* log_scale;        // [R]
+  double* rescales;         // [R][n_steps]
+  double min_norm;
+  int64_t out_numel;
+  int32_t n_steps, R, id_out, n_tensors, stabilize;
+};
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+// Rescale factor of a tensor from its producer's partial sums (reference
+// einsum.py:97-102: norm = sum|T|, rescale = norm / numel, applied iff
+// norm > min_norm).  All 64 lanes of the calling wave must be active.
+template <typename T>
+__device__ __forceinline__ T producer_scale(const double* part, int P, double numel, double min_norm,
+                                            int r, bool* cond_out = nullptr) {
+  if (part == nullptr) {
+    if (cond_out) *cond_out = false;
+    return (T)1;
+  }
+  const int lane = threadIdx.x & 63;
+  double v = lane < P ? part[(size_t)r * kMaxPartials + lane] : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const T norm = (T)v;
+  const bool cond = norm > (T)min_norm;
+  if (cond_out) *cond_out = cond;
+  return cond ? norm / (T)numel : (T)1;
+}
+
+// Sum over the workgroup in a fixed order; result valid in every thread.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  double t = 0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// ---------------------------------------------------------------------------
+// K-element: one thread per output element.  Hyperedge (batch) products,
+// Khatri-Rao, traces, tiny GEMVs - everything that is not worth a tile.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_element(StepArgs a) {
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const T* __restrict__ A = (const T*)tp[a.idA];
+  const T* __restrict__ B = (const T*)tp[a.idB];
+  T* __restrict__ C = (T*)tp[a.idC];
+  const int64_t total = (int64_t)a.Bt * a.M * a.N;
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double absv = 0;
+  if (o < total) {
+    const int n = (int)(o % a.N);
+    const int64_t q = o / a.N;
+    const int m = (int)(q % a.M);
+    const int b = (int)(q / a.M);
+    const T* pa = A + a.obA[b] + a.omA[m];
+    const T* pb = B + a.obB[b] + a.onB[n];
+    // operands are normalised on load, (A/sA)*(B/sB), exactly like the reference's
+    // stabilize() output feeding the next step: bit-identical when the K sum is exact
+    T acc = 0;
+    for (int k = 0; k < a.K; ++k) acc = fma(pa[a.okA[k]] / sA, pb[a.okB[k]] / sB, acc);
+    const T v = acc;
+    C[a.obC[b] + a.omC[m] + a.onC[n]] = v;
+    absv = (double)fabs(v);
+  }
+  const double tot = block_sum(absv, red);
+  if (threadIdx.x == 0) a.partC[(size_t)r * a.partC_stride + blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// K-dot: one workgroup per output element, K split over 256 lanes.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_dot(StepArgs a) {
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const T* __restrict__ A = (const T*)tp[a.idA];
+  const T* __restrict__ B = (const T*)tp[a.idB];
+  T* __restrict__ C = (T*)tp[a.idC];
+  const int o = blockIdx.x;
+  const int n = o % a.N;
+  const int q = o / a.N;
+  const int m = q % a.M;
+  const int b = q / a.M;
+  const T* pa = A + a.obA[b] + a.omA[m];
+  const T* pb = B + a.obB[b] + a.onB[n];
+  T acc = 0;
+  for (int k = threadIdx.x; k < a.K; k += 256) acc = fma(pa[a.okA[k]] / sA, pb[a.okB[k]] / sB, acc);
+  const T tot = (T)block_sum((double)acc, red);
+  if (threadIdx.x == 0) {
+    const T v = tot;
+    C[a.obC[b] + a.omC[m] + a.onC[n]] = v;
+    a.partC[(size_t)r * a.partC_stride + o] = (double)fabs(v);
+  }
+}
+
+// Collapse > 64 per-workgroup partials into one, in a fixed order.
+__global__ __launch_bounds__(256) void k_collapse(const double* scratch, int blocks, double* part) {
+  __shared__ double red[4];
+  const int r = blockIdx.x;
+  const double* src = scratch + (size_t)r * blocks;
+  double v = 0;
+  for (int i = threadIdx.x; i < blocks; i += 256) v += src[i];
+  const double tot = block_sum(v, red);
+  if (threadIdx.x == 0) part[(size_t)r * kMaxPartials] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// Finishing pass: normalise the final tensor, accumulate the log-scale
+// register (reference einsum.py:103-106) and dump every step's rescale factor.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_finalize(FinalArgs f) {
+  const int r = blockIdx.y;
+  const int last = f.n_steps - 1;
+  T s_last = (T)1;
+  if (f.stabilize)
+    s_last = producer_scale<T>(f.partials + (size_t)last * f.R * kMaxPartials, f.stepP[last],
+                               f.stepNumel[last], f.min_norm, r);
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    double ls = 0;
+    for (int s = 0; s < f.n_steps; ++s) {
+      bool cond = false;
+      T sc = (T)1;
+      if (f.stabilize)
+        sc = producer_scale<T>(f.partials + (size_t)s * f.R * kMaxPartials, f.stepP[s], f.stepNumel[s],
+                               f.min_norm, r, &cond);
+      if (cond) ls += (double)log(sc);
+      if (threadIdx.x == 0) f.rescales[(size_t)r * f.n_steps + s] = cond ? (double)sc : 0.0;
+    }
+    if (threadIdx.x == 0) f.log_scale[r] = ls;
+  }
+  if (!f.stabilize) return;
+  T* out = (T*)f.ptrs[(size_t)r * f.n_tensors + f.id_out];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < f.out_numel; i += (int64_t)gridDim.x * 256)
+    out[i] = out[i] / s_last;
+}
+
+// ---------------------------------------------------------------------------
+// K-mfma-f32: 128x128 workgroup tile, 4 waves (2x2), each wave 64x64 =
+// 2x2 v_mfma_f32_32x32x2_f32 accumulators, BK=16, register-staged double-buffered LDS.
+//
+// MODE (per operand): 0 scalar gather, 1 float4 along the free index (LDS image
+// [k][m]), 2 float4 along k (LDS image [m][k+1], odd row length => conflict-free
+// ds_read_b32 for the MFMA fragment: lane l reads row l&31, k = 2*kk + (l>>5)).
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = kTileM, BN = kTileN, BK = 16;
+
+template <int MODE>
+struct TileLoader {
+  // registers holding one 128 x BK operand tile slice of this thread (8 floats)
+  float v[8];
+  int offm[MODE == 0 ? 1 : 2];  // hoisted free-index offsets
+  bool okm[MODE == 0 ? 1 : 2];
+
+  __device__ __forceinline__ void init(const int32_t* om, int m0, int M, int tid) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 256;
+        const int gm = m0 + (f & 31) * 4;
+        offm[i] = om[gm];
+        okm[i] = gm < M;
+      }
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 256;
+        const int gm = m0 + (f >> 2);
+        offm[i] = om[gm];
+        okm[i] = gm < M;
+      }
+    } else {
+      const int gm = m0 + (tid & 127);
+      offm[0] = om[gm];
+      okm[0] = gm < M;
+    }
+  }
+
+  __device__ __forceinline__ void load(const float* __restrict__ base, const int32_t* __restrict__ ok,
+                                       int k0, int K, int tid) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 256;
+        const int gk = k0 + (f >> 5);
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (okm[i] && gk < K) x = *reinterpret_cast<const float4*>(base + offm[i] + ok[gk]);
+        v[4 * i + 0] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+      }
+    } else if (MODE == 2) {
+      const int gk = k0 + (tid & 3) * 4;
+      const bool kin = gk < K;
+      const int offk = ok[gk];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (okm[i] && kin) x = *reinterpret_cast<const float4*>(base + offm[i] + offk);
+        v[4 * i + 0] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int gk = k0 + (tid >> 7) + 2 * i;
+        float x = 0.f;
+        if (okm[0] && gk < K) x = base[offm[0] + ok[gk]];
+        v[i] = x;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ s, int tid) const {
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 256;
+        *reinterpret_cast<float4*>(s + (f >> 5) * BM + (f & 31) * 4) =
+            make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+      }
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 256;
+        float* d = s + (f >> 2) * (BK + 1) + (f & 3) * 4;
+        d[0] = v[4 * i]; d[1] = v[4 * i + 1]; d[2] = v[4 * i + 2]; d[3] = v[4 * i + 3];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[((tid >> 7) + 2 * i) * BM + (tid & 127)] = v[i];
+    }
+  }
+
+  // LDS index of element (row, k) of the tile image
+  static __device__ __forceinline__ int idx(int row, int k) {
+    return MODE == 2 ? row * (BK + 1) + k : k * BM + row;
+  }
+  static constexpr int kSize = MODE == 2 ? BM * (BK + 1) : BK * BM;
+};
+
+template <int MA, int MB>
+__global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
+  constexpr int SZA = TileLoader<MA>::kSize, SZB = TileLoader<MB>::kSize;
+  __shared__ __attribute__((aligned(16))) float smem[2 * SZA + 2 * SZB + 4];
+  __shared__ int s_omC[BM], s_onC[BN];
+  __shared__ double red[4];
+  float* sA = smem;
+  float* sB = smem + 2 * SZA;
+
+  const int tid = threadIdx.x;
+  // XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs, so give each
+  // XCD a contiguous range of tiles (one replica's tiles share that XCD's L2).
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+  const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int r = pid / a.blocks_per_replica;
+  const int t = pid - r * a.blocks_per_replica;
+  const int tiles_mn = a.tiles_m * a.tiles_n;
+  const int b = t / tiles_mn;
+  const int tt = t - b * tiles_mn;
+  const int m0 = (tt / a.tiles_n) * BM;
+  const int n0 = (tt % a.tiles_n) * BN;
+
+  const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
+
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
+  const float* __restrict__ B = (const float*)tp[a.idB] + a.obB[b];
+  float* __restrict__ C = (float*)tp[a.idC] + a.obC[b];
+
+  if (tid < BM) s_omC[tid] = a.omC[m0 + tid];
+  else s_onC[tid - BM] = a.onC[n0 + tid - BM];
+
+  TileLoader<MA> la;
+  TileLoader<MB> lb;
+  la.init(a.omA, m0, a.M, tid);
+  lb.init(a.onB, n0, a.N, tid);
+
+  const int lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nkt = (a.K + BK - 1) / BK;
+  la.load(A, a.okA, 0, a.K, tid);
+  lb.load(B, a.okB, 0, a.K, tid);
+  la.store(sA, tid);
+  lb.store(sB, tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      la.load(A, a.okA, (kt + 1) * BK, a.K, tid);
+      lb.load(B, a.okB, (kt + 1) * BK, a.K, tid);
+    }
+    const float* cA = sA + cur * SZA;
+    const float* cB = sB + cur * SZB;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int k = kk * 2 + h;
+      const float a0 = cA[TileLoader<MA>::idx(wm + l31, k)];
+      const float a1 = cA[TileLoader<MA>::idx(wm + 32 + l31, k)];
+      const float b0 = cB[TileLoader<MB>::idx(wn + l31, k)];
+      const float b1 = cB[TileLoader<MB>::idx(wn + 32 + l31, k)];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+      la.store(sA + (cur ^ 1) * SZA, tid);
+      lb.store(sB + (cur ^ 1) * SZB, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lazy rescale, store through the C offset tables, abs-sum partial
+  const float iA = 1.0f / scA, iB = 1.0f / scB;
+  float asum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wn + j * 32 + l31;
+      const bool cin = n0 + col < a.N;
+      const int offn = s_onC[col];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (cin && m0 + row < a.M) {
+          const float v = (acc[i][j][e] * iA) * iB;
+          C[s_omC[row] + offn] = v;
+          asum += fabsf(v);
+        }
+      }
+    }
+  }
+  const double tot = block_sum((double)asum, red);
+  if (tid == 0) a.partC[(size_t)r * a.partC_stride + t] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// executor
+// ---------------------------------------------------------------------------
+thread_local std::string g_err;
+
+#define HIPCHECK(expr)                                                                   \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+      return CTN_HIP_ERROR;                                                              \
+    }                                                                                    \
+  } while (0)
+
+struct Exec {
+  const Plan* plan = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int R = 1;
+  int n_tensors = 0;
+  char* d_ws = nullptr;
+  int32_t* d_tables = nullptr;
+  void** d_ptrs = nullptr;
+  std::vector<void*> h_ptrs;
+  bool ptrs_valid = false;
+  double* d_partials = nullptr;
+  double* d_scratch = nullptr;
+  double* d_log = nullptr;
+  double* d_resc = nullptr;
+  void* d_ones = nullptr;
+  int32_t* d_stepP = nullptr;
+  double* d_stepNumel = nullptr;
+  char* d_stage_in = nullptr;
+  char* d_stage_out = nullptr;
+  bool timing = false;
+  std::vector<hipEvent_t> events;  // 2 per step
+  bool events_recorded = false;
+
+  ~Exec() {
+    (void)hipSetDevice(device);
+    for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch,
+                    (void*)d_log, (void*)d_resc, d_ones, (void*)d_stepP, (void*)d_stepNumel,
+                    (void*)d_stage_in, (void*)d_stage_out})
+      if (p) (void)hipFree(p);
+    for (auto ev : events) (void)hipEventDestroy(ev);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+template <int MA>
+static void launch_mfma_b(int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
+  switch (mb) {
+    case 1: hipLaunchKernelGGL((k_mfma_f32<MA, 1>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_mfma_f32<MA, 2>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_mfma_f32<MA, 0>), grid, dim3(256), 0, st, a); break;
+  }
+}
+
+static void launch_mfma(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
+  switch (ma) {
+    case 1: launch_mfma_b<1>(mb, grid, st, a); break;
+    case 2: launch_mfma_b<2>(mb, grid, st, a); break;
+    default: launch_mfma_b<0>(mb, grid, st, a); break;
+  }
+}
+
+static int exec_launch_all(Exec* E) {
+  const Plan& P = *E->plan;
+  const int R = E->R;
+  for (int s = 0; s < P.n_steps; ++s) {
+    const Step& st = P.steps[s];
+    StepArgs a;
+    const int32_t* T = E->d_tables;
+    a.obA = T + st.t.obA; a.obB = T + st.t.obB; a.obC = T + st.t.obC;
+    a.omA = T + st.t.omA; a.omC = T + st.t.omC;
+    a.onB = T + st.t.onB; a.onC = T + st.t.onC;
+    a.okA = T + st.t.okA; a.okB = T + st.t.okB;
+    a.ptrs = E->d_ptrs;
+    auto part_of = [&](int id, const double** p, int32_t* cnt, double* numel) {
+      *p = nullptr; *cnt = 0; *numel = 1;
+      if (id >= P.n_inputs && P.stabilize) {
+        const int ps = P.tensors[id].producer;
+        *p = E->d_partials + (size_t)ps * R * kMaxPartials;
+        *cnt = P.steps[ps].partials;
+        *numel = (double)P.tensors[id].numel;
+      }
+    };
+    part_of(st.lhs, &a.partA, &a.PA, &a.numelA);
+    part_of(st.rhs, &a.partB, &a.PB, &a.numelB);
+    double* part_dst = E->d_partials + (size_t)s * R * kMaxPartials;
+    a.partC = st.collapse ? E->d_scratch : part_dst;
+    a.partC_stride = st.collapse ? st.blocks : kMaxPartials;
+    a.min_norm = P.min_norm;
+    a.Bt = (int32_t)st.Bt; a.M = (int32_t)st.M; a.N = (int32_t)st.N; a.K = (int32_t)st.K;
+    a.idA = st.lhs; a.idB = st.rhs >= 0 ? st.rhs : E->n_tensors - 1; a.idC = st.out;
+    a.n_tensors = E->n_tensors;
+    a.tiles_m = (int32_t)((st.M + kTileM - 1) / kTileM);
+    a.tiles_n = (int32_t)((st.N + kTileN - 1) / kTileN);
+    a.blocks_per_replica = st.blocks;
+    a.R = R;
+
+    if (E->timing) HIPCHECK(hipEventRecord(E->events[2 * s], E->stream));
+    switch (st.kernel) {
+      case CTN_KERNEL_MFMA_F32: {
+        const int64_t total = (int64_t)st.blocks * R;
+        if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
+        launch_mfma(st.modeA, st.modeB, dim3((unsigned)total), E->stream, a);
+        break;
+      }
+      case CTN_KERNEL_DOT:
+        if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_dot<float>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
+        else hipLaunchKernelGGL(k_dot<double>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
+        break;
+      default:
+        if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_element<float>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
+        else hipLaunchKernelGGL(k_element<double>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
+        break;
+    }
+    if (st.collapse)
+      hipLaunchKernelGGL(k_collapse, dim3(R), dim3(256), 0, E->stream, (const double*)E->d_scratch, st.blocks, part_dst);
+    if (E->timing) HIPCHECK(hipEventRecord(E->events[2 * s + 1], E->stream));
+  }
+  FinalArgs f;
+  f.ptrs = E->d_ptrs;
+  f.partials = E->d_partials;
+  f.stepP = E->d_stepP;
+  f.stepNumel = E->d_stepNumel;
+  f.log_scale = E->d_log;
+  f.rescales = E->d_resc;
+  f.min_norm = P.min_norm;
+  f.out_numel = P.output().numel;
+  f.n_steps = P.n_steps; f.R = R; f.id_out = P.n_inputs + P.n_steps - 1; f.n_tensors = E->n_tensors;
+  f.stabilize = P.stabilize ? 1 : 0;
+  int fb = (int)std::min<int64_t>((P.output().numel + 255) / 256, 1024);
+  if (fb < 1) fb = 1;
+  if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_finalize<float>, dim3(fb, R), dim3(256), 0, E->stream, f);
+  else hipLaunchKernelGGL(k_finalize<double>, dim3(fb, R), dim3(256), 0, E->stream, f);
+  HIPCHECK(hipGetLastError());
+  E->events_recorded = E->timing;
+  return CTN_OK;
+}
+
+static int exec_set_pointers(Exec* E, const void* const* dev_inputs, void* const* dev_outs) {
+  const Plan& P = *E->plan;
+  const int nt = E->n_tensors;
+  bool changed = !E->ptrs_valid;
+  for (int r = 0; r < E->R; ++r) {
+    void** row = E->h_ptrs.data() + (size_t)r * nt;
+    for (int i = 0; i < P.n_inputs; ++i) {
+      void* p = const_cast<void*>(dev_inputs[(size_t)r * P.n_inputs + i]);
+      if (!p) { g_err = "null operand pointer"; return CTN_INVALID_ARG; }
+      if ((uintptr_t)p % 16) { g_err = "operand pointers must be 16-byte aligned"; return CTN_INVALID_ARG; }
+      if (row[i] != p) { row[i] = p; changed = true; }
+    }
+    void* o = dev_outs[r];
+    if (!o) { g_err = "null output pointer"; return CTN_INVALID_ARG; }
+    if ((uintptr_t)o % 16) { g_err = "output pointers must be 16-byte aligned"; return CTN_INVALID_ARG; }
+    const int id_out = P.n_inputs + P.n_steps - 1;
+    if (row[id_out] != o) { row[id_out] = o; changed = true; }
+  }
+  if (changed) {
+    HIPCHECK(hipMemcpyAsync(E->d_ptrs, E->h_ptrs.data(), E->h_ptrs.size() * sizeof(void*),
+                            hipMemcpyHostToDevice, E->stream));
+    E->ptrs_valid = true;
+  }
+  return CTN_OK;
+}
+
+}  // namespace ctn
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+using namespace ctn;
+
+struct ctn_plan { Plan p; };
+struct ctn_exec { Exec e; };
+
+extern "C" {
+
+int ctn_version(void) { return CTN_ABI_VERSION; }
+
+const char* ctn_last_error(void) { return g_err.c_str(); }
+
+int ctn_device_count(int* count) {
+  if (!count) { g_err = "count is NULL"; return CTN_INVALID_ARG; }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    *count = 0;
+    g_err = std::string("no HIP device available: ") + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return CTN_NO_DEVICE;
+  }
+  *count = n;
+  return CTN_OK;
+}
+
+int ctn_plan_create(const ctn_plan_desc* desc, ctn_plan** out) {
+  if (!desc || !out) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+  *out = nullptr;
+  ctn_plan* p = new (std::nothrow) ctn_plan();
+  if (!p) { g_err = "out of host memory"; return CTN_OOM; }
+  std::string err;
+  int rc = CTN_OK;
+  try {
+    rc = build_plan(*desc, p->p, err);
+  } catch (const std::bad_alloc&) {
+    rc = CTN_OOM; err = "out of host memory while building the plan";
+  } catch (const std::exception& ex) {
+    rc = CTN_INVALID_ARG; err = ex.what();
+  }
+  if (rc != CTN_OK) { g_err = err; delete p; return rc; }
+  *out = p;
+  return CTN_OK;
+}
+
+void ctn_plan_destroy(ctn_plan* plan) { delete plan; }
+int ctn_plan_dtype(const ctn_plan* plan) { return plan ? plan->p.dtype : CTN_INVALID_ARG; }
+int ctn_plan_n_inputs(const ctn_plan* plan) { return plan ? plan->p.n_inputs : CTN_INVALID_ARG; }
+int ctn_plan_n_steps(const ctn_plan* plan) { return plan ? plan->p.n_steps : CTN_INVALID_ARG; }
+double ctn_plan_flops(const ctn_plan* plan) { return plan ? plan->p.flops : 0.0; }
+int64_t ctn_plan_bytes_min(const ctn_plan* plan) { return plan ? plan->p.bytes_min : 0; }
+int ctn_plan_out_ndim(const ctn_plan* plan) { return plan ? (int)plan->p.output().dims.size() : CTN_INVALID_ARG; }
+int ctn_plan_out_dims(const ctn_plan* plan, int64_t* dims) {
+  if (!plan || !dims) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+  const auto& d = plan->p.output().dims;
+  for (size_t i = 0; i < d.size(); ++i) dims[i] = d[i];
+  return CTN_OK;
+}
+int64_t ctn_plan_out_numel(const ctn_plan* plan) { return plan ? plan->p.output().numel : 0; }
+int64_t ctn_plan_out_bytes(const ctn_plan* plan) {
+  return plan ? plan->p.output().numel * (int64_t)plan->p.elem_size() : 0;
+}
+
+static int64_t exec_fixed_bytes(const Plan& P, int R) {
+  const int nt = P.n_inputs + P.n_steps + 1;
+  return (int64_t)P.tables.size() * 4 + (int64_t)R * nt * 8 + (int64_t)P.n_steps * R * kMaxPartials * 8 +
+         (int64_t)R * std::max<int64_t>(P.max_collapse_blocks, 1) * 8 + (int64_t)R * 8 +
+         (int64_t)R * P.n_steps * 8 + 256 + (int64_t)P.n_steps * 12;
+}
+
+int64_t ctn_plan_workspace_bytes(const ctn_plan* plan, int replicas) {
+  if (!plan || replicas < 1) return 0;
+  return plan->p.ws_bytes_per_replica * replicas + exec_fixed_bytes(plan->p, replicas);
+}
+
+int ctn_plan_step_info(const ctn_plan* plan, int step, ctn_step_info* info) {
+  if (!plan || !info || step < 0 || step >= plan->p.n_steps) { g_err = "invalid step query"; return CTN_INVALID_ARG; }
+  const Step& s = plan->p.steps[step];
+  info->kernel = s.kernel;
+  info->swapped = s.swapped ? 1 : 0;
+  info->batch = s.Bt; info->m = s.M; info->n = s.N; info->k = s.K;
+  info->mode_a = s.modeA; info->mode_b = s.modeB;
+  info->partials = s.partials; info->blocks = s.blocks;
+  info->flops = s.flops;
+  info->out_numel = plan->p.tensors[s.out].numel;
+  return CTN_OK;
+}
+
+int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas, ctn_exec** out) {
+  if (!plan || !out || replicas < 1) { g_err = "invalid argument to ctn_exec_create"; return CTN_INVALID_ARG; }
+  *out = nullptr;
+  int ndev = 0;
+  int rc = ctn_device_count(&ndev);
+  if (rc != CTN_OK) return rc;
+  if (device < 0 || device >= ndev) { g_err = "device index out of range"; return CTN_INVALID_ARG; }
+  HIPCHECK(hipSetDevice(device));
+  ctn_exec* x = new (std::nothrow) ctn_exec();
+  if (!x) { g_err = "out of host memory"; return CTN_OOM; }
+  Exec& E = x->e;
+  const Plan& P = plan->p;
+  E.plan = &P; E.device = device; E.R = replicas;
+  E.n_tensors = P.n_inputs + P.n_steps + 1;
+  auto fail = [&](int code) { delete x; return code; };
+#define HIPCHECK_X(expr)                                                        \
+  do {                                                                          \
+    hipError_t e_ = (expr);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                \
+      return fail(e_ == hipErrorOutOfMemory ? CTN_OOM : CTN_HIP_ERROR);         \
+    }                                                                           \
+  } while (0)
+  if (stream) { E.stream = (hipStream_t)stream; }
+  else { HIPCHECK_X(hipStreamCreateWithFlags(&E.stream, hipStreamNonBlocking)); E.own_stream = true; }
+  const size_t ws = (size_t)std::max<int64_t>(P.ws_bytes_per_replica, 256) * replicas;
+  HIPCHECK_X(hipMalloc((void**)&E.d_ws, ws));
+  HIPCHECK_X(hipMalloc((void**)&E.d_tables, std::max<size_t>(P.tables.size(), 4) * 4));
+  HIPCHECK_X(hipMemcpy(E.d_tables, P.tables.data(), P.tables.size() * 4, hipMemcpyHostToDevice));
+  HIPCHECK_X(hipMalloc((void**)&E.d_ptrs, (size_t)replicas * E.n_tensors * sizeof(void*)));
+  HIPCHECK_X(hipMalloc((void**)&E.d_partials, (size_t)P.n_steps * replicas * kMaxPartials * 8));
+  HIPCHECK_X(hipMemset(E.d_partials, 0, (size_t)P.n_steps * replicas * kMaxPartials * 8));
+  HIPCHECK_X(hipMalloc((void**)&E.d_scratch, (size_t)replicas * std::max<int64_t>(P.max_collapse_blocks, 1) * 8));
+  HIPCHECK_X(hipMalloc((void**)&E.d_log, (size_t)replicas * 8));
+  HIPCHECK_X(hipMalloc((void**)&E.d_resc, (size_t)replicas * P.n_steps * 8));
+  HIPCHECK_X(hipMalloc(&E.d_ones, 256));
+  {
+    double one64 = 1.0; float one32 = 1.0f;
+    if (P.dtype == CTN_F64) HIPCHECK_X(hipMemcpy(E.d_ones, &one64, 8, hipMemcpyHostToDevice));
+    else HIPCHECK_X(hipMemcpy(E.d_ones, &one32, 4, hipMemcpyHostToDevice));
+  }
+  std::vector<int32_t> sp(P.n_steps);
+  std::vector<double> sn(P.n_steps);
+  for (int s = 0; s < P.n_steps; ++s) { sp[s] = P.steps[s].partials; sn[s] = (double)P.tensors[P.steps[s].out].numel; }
+  HIPCHECK_X(hipMalloc((void**)&E.d_stepP, P.n_steps * 4));
+  HIPCHECK_X(hipMalloc((void**)&E.d_stepNumel, P.n_steps * 8));
+  HIPCHECK_X(hipMemcpy(E.d_stepP, sp.data(), P.n_steps * 4, hipMemcpyHostToDevice));
+  HIPCHECK_X(hipMemcpy(E.d_stepNumel, sn.data(), P.n_steps * 8, hipMemcpyHostToDevice));
+  // pointer table: intermediates and the ones-scalar are fixed for the executor's lifetime
+  E.h_ptrs.assign((size_t)replicas * E.n_tensors, nullptr);
+  for (int r = 0; r < replicas; ++r) {
+    void** row = E.h_ptrs.data() + (size_t)r * E.n_tensors;
+    for (int id = P.n_inputs; id < P.n_inputs + P.n_steps - 1; ++id)
+      row[id] = E.d_ws + (size_t)r * P.ws_bytes_per_replica + P.tensors[id].ws_offset;
+    row[E.n_tensors - 1] = E.d_ones;
+  }
+#undef HIPCHECK_X
+  *out = x;
+  return CTN_OK;
+}
+
+void ctn_exec_destroy(ctn_exec* exec) { delete exec; }
+
+int ctn_exec_enqueue(ctn_exec* exec, const void* const* dev_inputs, void* const* dev_outs) {
+  if (!exec || !dev_inputs || !dev_outs) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+  Exec* E = &exec->e;
+  HIPCHECK(hipSetDevice(E->device));
+  int rc = exec_set_pointers(E, dev_inputs, dev_outs);
+  if (rc != CTN_OK) return rc;
+  return exec_launch_all(E);
+}
+
+int ctn_exec_synchronize(ctn_exec* exec) {
+  if (!exec) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+  HIPCHECK(hipStreamSynchronize(exec->e.stream));
+  return CTN_OK;
+}
+
+int ctn_exec_fetch(ctn_exec* exec, double* log_scale, double* step_rescales) {
+  if (!exec) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+  Exec* E = &exec->e;
+  HIPCHECK(hipSetDevice(E->device));
+  if (log_scale)
+    HIPCHECK(hipMemcpyAsync(log_scale, E->d_log, (size_t)E->R * 8, hipMemcpyDeviceToHost, E->stream));
+  if (step_rescales)
+    HIPCHECK(hipMemcpyAsync(step_rescales, E->d_resc, (size_t)E->R * E->plan->n_steps * 8,
+                            hipMemcpyDeviceToHost, E->stream));
+  HIPCHECK(hipStreamSynchronize(E->stream));
+  return CTN_OK;
+}
+
+int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space, void* const* outs,
+                 int outs_space, double* log_scale, double* step_rescales) {
+  if (!exec || !inputs || !outs) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+  Exec* E = &exec->e;
+  const Plan& P = *E->plan;
+  HIPCHECK(hipSetDevice(E->device));
+  const size_t es = P.elem_size();
+  const int64_t out_bytes = P.output().numel * (int64_t)es;
+  const int64_t out_slot = (out_bytes + kAlign - 1) / kAlign * kAlign;
+  std::vector<const void*> din((size_t)E->R * P.n_inputs);
+  std::vector<void*> dout(E->R);
+  if (inputs_space == CTN_MEM_HOST) {
+    if (!E->d_stage_in) {
+      hipError_t e_ = hipMalloc((void**)&E->d_stage_in, (size_t)std::max<int64_t>(P.input_bytes_per_replica, 256) * E->R);
+      if (e_ != hipSuccess) { g_err = "hipMalloc(input staging) failed"; return e_ == hipErrorOutOfMemory ? CTN_OOM : CTN_HIP_ERROR; }
+    }
+    for (int r = 0; r < E->R; ++r)
+      for (int i = 0; i < P.n_inputs; ++i) {
+        const void* src = inputs[(size_t)r * P.n_inputs + i];
+        if (!src) { g_err = "null operand pointer"; return CTN_INVALID_ARG; }
+        char* dst = E->d_stage_in + (size_t)r * P.input_bytes_per_replica + P.input_offsets[i];
+        HIPCHECK(hipMemcpyAsync(dst, src, (size_t)P.tensors[i].numel * es, hipMemcpyHostToDevice, E->stream));
+        din[(size_t)r * P.n_inputs + i] = dst;
+      }
+  } else {
+    for (size_t i = 0; i < din.size(); ++i) din[i] = inputs[i];
+  }
+  if (outs_space == CTN_MEM_HOST) {
+    if (!E->d_stage_out) {
+      hipError_t e_ = hipMalloc((void**)&E->d_stage_out, (size_t)out_slot * E->R);
+      if (e_ != hipSuccess) { g_err = "hipMalloc(output staging) failed"; return e_ == hipErrorOutOfMemory ? CTN_OOM : CTN_HIP_ERROR; }
+    }
+    for (int r = 0; r < E->R; ++r) dout[r] = E->d_stage_out + (size_t)r * out_slot;
+  } else {
+    for (int r = 0; r < E->R; ++r) dout[r] = outs[r];
+  }
+  int rc = exec_set_pointers(E, din.data(), dout.data());
+  if (rc != CTN_OK) return rc;
+  rc = exec_launch_all(E);
+  if (rc != CTN_OK) return rc;
+  if (outs_space == CTN_MEM_HOST)
+    for (int r = 0; r < E->R; ++r) {
+      if (!outs[r]) { g_err = "null output pointer"; return CTN_INVALID_ARG; }
+      HIPCHECK(hipMemcpyAsync(outs[r], dout[r], (size_t)out_bytes, hipMemcpyDeviceToHost, E->stream));
+    }
+  return ctn_exec_fetch(exec, log_scale, step_rescales);
+}
+
+int ctn_exec_set_timing(ctn_exec* exec, int enabled) {
+  if (!exec) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+  Exec* E = &exec->e;
+  HIPCHECK(hipSetDevice(E->device));
+  if (enabled && E->events.empty()) {
+    E->events.resize((size_t)2 * E->plan->n_steps);
+    for (auto& ev : E->events) HIPCHECK(hipEventCreate(&ev));
+  }
+  E->timing = enabled != 0;
+  if (!E->timing) E->events_recorded = false;
+  return CTN_OK;
+}
+
+int ctn_exec_step_ms(ctn_exec* exec, float* ms) {
+  if (!exec || !ms) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+  Exec* E = &exec->e;
+  if (!E->events_recorded) { g_err = "no timed run recorded: call ctn_exec_set_timing(1) then enqueue"; return CTN_INVALID_ARG; }
+  HIPCHECK(hipStreamSynchronize(E->stream));
+  for (int s = 0; s < E->plan->n_steps; ++s)
+    HIPCHECK(hipEventElapsedTime(&ms[s], E->events[2 * s], E->events[2 * s + 1]));
+  return CTN_OK;
+}
+
+}  // extern "C"

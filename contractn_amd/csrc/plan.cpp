@@ -1,0 +1,346 @@
+// plan.cpp - contraction-list lowering (host only, no HIP).  See plan.h.
+#include "plan.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <map>
+#include <numeric>
+
+namespace ctn {
+namespace {
+
+enum LabelClass { kBatch = 0, kM = 1, kN = 2, kK = 3 };
+
+struct LabelInfo {
+  int32_t label = 0;
+  int64_t ext = 0;
+  int64_t sA = 0, sB = 0, sC = 0;
+  bool inA = false, inB = false, inC = false;
+  int firstPos = 0;  // for stable ordering
+  int cls = kK;
+};
+
+std::string fmt(const char* f, long long a = 0, long long b = 0, long long c = 0) {
+  char buf[256];
+  snprintf(buf, sizeof buf, f, a, b, c);
+  return buf;
+}
+
+int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// Row-major enumeration of a label group: table[i] = sum_j idx_j * stride_j
+void build_table(const std::vector<const LabelInfo*>& group, int which /*0 A,1 B,2 C*/,
+                 int64_t padded, std::vector<int32_t>& out) {
+  int64_t n = 1;
+  for (auto* l : group) n *= l->ext;
+  out.assign(std::max<int64_t>(padded, n), 0);
+  std::vector<int64_t> idx(group.size(), 0);
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t off = 0;
+    for (size_t j = 0; j < group.size(); ++j) {
+      int64_t s = which == 0 ? group[j]->sA : which == 1 ? group[j]->sB : group[j]->sC;
+      off += idx[j] * s;
+    }
+    out[i] = (int32_t)off;
+    for (int j = (int)group.size() - 1; j >= 0; --j) {
+      if (++idx[j] < group[j]->ext) break;
+      idx[j] = 0;
+    }
+  }
+}
+
+// simple first-fit allocator over one replica's workspace
+struct Arena {
+  struct Block { int64_t off, size; };
+  std::vector<Block> free_list;
+  int64_t top = 0;
+  int64_t alloc(int64_t bytes) {
+    bytes = round_up(std::max<int64_t>(bytes, 1), kAlign);
+    for (size_t i = 0; i < free_list.size(); ++i) {
+      if (free_list[i].size >= bytes) {
+        int64_t off = free_list[i].off;
+        free_list[i].off += bytes;
+        free_list[i].size -= bytes;
+        if (free_list[i].size == 0) free_list.erase(free_list.begin() + i);
+        return off;
+      }
+    }
+    int64_t off = top;
+    top += bytes;
+    return off;
+  }
+  void release(int64_t off, int64_t bytes) {
+    bytes = round_up(std::max<int64_t>(bytes, 1), kAlign);
+    free_list.push_back({off, bytes});
+    std::sort(free_list.begin(), free_list.end(),
+              [](const Block& a, const Block& b) { return a.off < b.off; });
+    for (size_t i = 0; i + 1 < free_list.size();) {
+      if (free_list[i].off + free_list[i].size == free_list[i + 1].off) {
+        free_list[i].size += free_list[i + 1].size;
+        free_list.erase(free_list.begin() + i + 1);
+      } else {
+        ++i;
+      }
+    }
+  }
+};
+
+int64_t append(std::vector<int32_t>& all, const std::vector<int32_t>& t) {
+  // keep every table 16-byte aligned inside the device buffer
+  while (all.size() % 4) all.push_back(0);
+  int64_t off = (int64_t)all.size();
+  all.insert(all.end(), t.begin(), t.end());
+  return off;
+}
+
+}  // namespace
+
+int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
+  if (d.dtype != CTN_F32 && d.dtype != CTN_F64) { err = "dtype must be CTN_F32 or CTN_F64"; return CTN_INVALID_ARG; }
+  if (d.n_inputs < 1 || !d.in_ndim || (!d.in_dims && !d.in_labels)) { err = "plan needs at least one input"; return CTN_INVALID_ARG; }
+  if (d.n_steps < 1 || !d.step_lhs || !d.step_rhs || !d.step_out_ndim) { err = "plan needs at least one step"; return CTN_INVALID_ARG; }
+  P.dtype = d.dtype;
+  P.n_inputs = d.n_inputs;
+  P.n_steps = d.n_steps;
+  P.stabilize = d.stabilize != 0;
+  P.min_norm = d.min_norm;
+  const int64_t es = (int64_t)P.elem_size();
+  const int64_t vec = 16 / es;  // elements per 16-byte vector load
+
+  // ---- inputs ---------------------------------------------------------------
+  std::map<int32_t, int64_t> label_ext;
+  P.tensors.clear();
+  P.tensors.reserve(d.n_inputs + d.n_steps);
+  int64_t cur = 0;
+  int64_t in_bytes = 0;
+  P.input_offsets.clear();
+  for (int i = 0; i < d.n_inputs; ++i) {
+    Tensor t;
+    t.is_input = true;
+    int nd = d.in_ndim[i];
+    if (nd < 0 || nd > 64) { err = fmt("input %lld has invalid ndim %lld", i, nd); return CTN_INVALID_ARG; }
+    for (int a = 0; a < nd; ++a) {
+      int64_t ext = d.in_dims[cur + a];
+      int32_t lab = d.in_labels[cur + a];
+      if (ext < 1) { err = fmt("input %lld axis %lld has extent %lld (must be >= 1)", i, a, ext); return CTN_SHAPE_MISMATCH; }
+      auto it = label_ext.find(lab);
+      if (it == label_ext.end()) label_ext[lab] = ext;
+      else if (it->second != ext) {
+        err = fmt("label %lld has extent %lld in one operand and %lld in another", lab, it->second, ext);
+        return CTN_SHAPE_MISMATCH;
+      }
+      t.labels.push_back(lab);
+      t.dims.push_back(ext);
+      t.numel *= ext;
+    }
+    t.strides.assign(nd, 1);
+    if (d.in_strides) {
+      for (int a = 0; a < nd; ++a) t.strides[a] = d.in_strides[cur + a];
+    } else {
+      for (int a = nd - 2; a >= 0; --a) t.strides[a] = t.strides[a + 1] * t.dims[a + 1];
+    }
+    if (t.numel >= (1LL << 31)) { err = "tensors with >= 2^31 elements are not supported"; return CTN_UNSUPPORTED; }
+    cur += nd;
+    P.input_offsets.push_back(in_bytes);
+    in_bytes += round_up(t.numel * es, kAlign);
+    P.bytes_min += t.numel * es;
+    P.tensors.push_back(std::move(t));
+  }
+  P.input_bytes_per_replica = in_bytes;
+
+  // ---- steps ----------------------------------------------------------------
+  std::vector<int> consumed(d.n_inputs + d.n_steps, 0);
+  Arena arena;
+  P.steps.clear();
+  P.tables.clear();
+  int64_t out_cur = 0;
+  for (int s = 0; s < d.n_steps; ++s) {
+    Step st;
+    const int out_id = d.n_inputs + s;
+    int lhs = d.step_lhs[s], rhs = d.step_rhs[s];
+    const bool last = s == d.n_steps - 1;
+    if (lhs < 0 || lhs >= out_id || rhs < -1 || rhs >= out_id || lhs == rhs) {
+      err = fmt("step %lld references invalid operands (%lld, %lld)", s, lhs, rhs);
+      return CTN_INVALID_ARG;
+    }
+    if (consumed[lhs] || (rhs >= 0 && consumed[rhs])) {
+      err = fmt("step %lld consumes a tensor that was already contracted away", s);
+      return CTN_INVALID_ARG;
+    }
+    consumed[lhs] = 1;
+    if (rhs >= 0) consumed[rhs] = 1;
+
+    const int ond = d.step_out_ndim[s];
+    std::vector<int32_t> out_labels(d.step_out_labels + out_cur, d.step_out_labels + out_cur + ond);
+    out_cur += ond;
+
+    // -- label census
+    std::vector<LabelInfo> info;
+    auto find = [&](int32_t lab) -> LabelInfo* {
+      for (auto& l : info) if (l.label == lab) return &l;
+      return nullptr;
+    };
+    auto scan = [&](const Tensor& T, bool isA) {
+      for (size_t a = 0; a < T.labels.size(); ++a) {
+        LabelInfo* l = find(T.labels[a]);
+        if (!l) {
+          info.emplace_back();
+          l = &info.back();
+          l->label = T.labels[a];
+          l->ext = T.dims[a];
+          l->firstPos = (int)info.size();
+        }
+        (isA ? l->sA : l->sB) += T.strides[a];  // repeated label = diagonal: strides add
+        (isA ? l->inA : l->inB) = true;
+      }
+    };
+    scan(P.tensors[lhs], true);
+    if (rhs >= 0) scan(P.tensors[rhs], false);
+    for (size_t a = 0; a < out_labels.size(); ++a) {
+      LabelInfo* l = find(out_labels[a]);
+      if (!l) { err = fmt("step %lld: output label %lld is in neither operand", s, out_labels[a]); return CTN_INVALID_ARG; }
+      if (l->inC) { err = fmt("step %lld: output label %lld is repeated", s, out_labels[a]); return CTN_INVALID_ARG; }
+      l->inC = true;
+    }
+
+    // -- operand swap: the output's unit-stride label should be a column (N) label
+    bool swap = false;
+    if (rhs >= 0) {
+      if (last) {
+        if (!out_labels.empty()) {
+          LabelInfo* l = find(out_labels.back());
+          if (l->inA && !l->inB) swap = true;
+        }
+      } else {
+        bool anyM = false, anyN = false;
+        for (auto& l : info) if (l.inC) { if (l.inA && !l.inB) anyM = true; if (l.inB && !l.inA) anyN = true; }
+        if (anyM && !anyN) swap = true;
+      }
+    }
+    if (swap) {
+      std::swap(lhs, rhs);
+      for (auto& l : info) { std::swap(l.sA, l.sB); std::swap(l.inA, l.inB); }
+    }
+    st.lhs = lhs; st.rhs = rhs; st.out = out_id; st.swapped = swap;
+
+    // -- classify and order
+    std::vector<LabelInfo*> G[4];
+    for (auto& l : info) {
+      l.cls = l.inC ? (l.inA && l.inB ? kBatch : (l.inA ? kM : kN)) : kK;
+      G[l.cls].push_back(&l);
+    }
+    auto by = [](bool useA) {
+      return [useA](const LabelInfo* x, const LabelInfo* y) {
+        // labels absent from the ordering operand (summed out of the other one) go outermost
+        int64_t sx = useA ? (x->inA ? x->sA : INT64_MAX) : (x->inB ? x->sB : INT64_MAX);
+        int64_t sy = useA ? (y->inA ? y->sA : INT64_MAX) : (y->inB ? y->sB : INT64_MAX);
+        if (sx != sy) return sx > sy;  // descending stride: last label is the most contiguous
+        return x->firstPos < y->firstPos;
+      };
+    };
+    std::stable_sort(G[kBatch].begin(), G[kBatch].end(), by(true));
+    std::stable_sort(G[kM].begin(), G[kM].end(), by(true));
+    std::stable_sort(G[kN].begin(), G[kN].end(), by(false));
+    bool aUnitInK = false, bUnitInK = false;
+    for (auto* l : G[kK]) { if (l->inA && l->sA == 1) aUnitInK = true; if (l->inB && l->sB == 1) bUnitInK = true; }
+    std::stable_sort(G[kK].begin(), G[kK].end(), by(!(bUnitInK && !aUnitInK)));
+
+    // -- output tensor and its layout
+    Tensor out;
+    out.producer = s;
+    if (last) {
+      out.labels = out_labels;
+    } else {
+      for (int c : {kBatch, kM, kN}) for (auto* l : G[c]) out.labels.push_back(l->label);
+    }
+    for (int32_t lab : out.labels) out.dims.push_back(find(lab)->ext);
+    out.strides.assign(out.labels.size(), 1);
+    for (int a = (int)out.labels.size() - 2; a >= 0; --a) out.strides[a] = out.strides[a + 1] * out.dims[a + 1];
+    for (size_t a = 0; a < out.labels.size(); ++a) { out.numel *= out.dims[a]; find(out.labels[a])->sC = out.strides[a]; }
+    if (out.numel >= (1LL << 31)) { err = "tensors with >= 2^31 elements are not supported"; return CTN_UNSUPPORTED; }
+
+    auto extent = [](const std::vector<LabelInfo*>& g) { int64_t n = 1; for (auto* l : g) n *= l->ext; return n; };
+    st.Bt = extent(G[kBatch]); st.M = extent(G[kM]); st.N = extent(G[kN]); st.K = extent(G[kK]);
+    st.has_k = !G[kK].empty();
+    if (st.Bt >= (1LL << 31) || st.M >= (1LL << 31) || st.N >= (1LL << 31) || st.K >= (1LL << 31)) {
+      err = "index group with >= 2^31 entries is not supported"; return CTN_UNSUPPORTED;
+    }
+
+    // -- vector-load modes: 1 = unit stride on the free index, 2 = unit stride on k
+    auto mode_of = [&](bool isA) -> int {
+      auto stride = [&](const LabelInfo* l) { return isA ? l->sA : l->sB; };
+      auto present = [&](const LabelInfo* l) { return isA ? l->inA : l->inB; };
+      const auto& freeG = isA ? G[kM] : G[kN];
+      auto others_ok = [&](const LabelInfo* unit) {
+        for (auto& l : info) if (&l != unit && present(&l) && stride(&l) % vec != 0) return false;
+        return true;
+      };
+      if (!freeG.empty()) {
+        const LabelInfo* l = freeG.back();
+        if (stride(l) == 1 && l->ext % vec == 0 && others_ok(l)) return 1;
+      }
+      if (!G[kK].empty()) {
+        const LabelInfo* l = G[kK].back();
+        if (present(l) && stride(l) == 1 && l->ext % vec == 0 && others_ok(l)) return 2;
+      }
+      return 0;
+    };
+    st.modeA = mode_of(true);
+    st.modeB = rhs >= 0 ? mode_of(false) : 0;
+
+    // -- kernel choice
+    const int64_t outs = st.Bt * st.M * st.N;
+    if (P.dtype == CTN_F32 && st.M >= 32 && st.N >= 32 && st.K >= 8) {
+      st.kernel = CTN_KERNEL_MFMA_F32;
+      st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + kTileN - 1) / kTileN));
+    } else if (kEnableMfmaF64 && P.dtype == CTN_F64 && st.M >= 32 && st.N >= 32 && st.K >= 8) {
+      st.kernel = CTN_KERNEL_MFMA_F64;
+      st.blocks = (int)(st.Bt * ((st.M + kTile64 - 1) / kTile64) * ((st.N + kTile64 - 1) / kTile64));
+    } else if (outs <= kMaxPartials && st.K >= 512) {
+      st.kernel = CTN_KERNEL_DOT;
+      st.blocks = (int)outs;
+    } else {
+      st.kernel = CTN_KERNEL_ELEMENT;
+      int64_t b = (outs + 255) / 256;
+      if (b >= (1LL << 31)) { err = "step output too large"; return CTN_UNSUPPORTED; }
+      st.blocks = (int)b;
+    }
+    st.collapse = st.blocks > kMaxPartials;
+    st.partials = st.collapse ? 1 : st.blocks;
+    if (st.collapse) P.max_collapse_blocks = std::max<int64_t>(P.max_collapse_blocks, st.blocks);
+    st.flops = (st.has_k ? 2.0 : 1.0) * (double)st.Bt * (double)st.M * (double)st.N * (double)st.K +
+               (P.stabilize ? 3.0 * (double)out.numel : 0.0);
+    P.flops += st.flops;
+
+    // -- gather-offset tables
+    std::vector<const LabelInfo*> gb(G[kBatch].begin(), G[kBatch].end()), gm(G[kM].begin(), G[kM].end()),
+        gn(G[kN].begin(), G[kN].end()), gk(G[kK].begin(), G[kK].end());
+    const int64_t padM = round_up(st.M, kTileM), padN = round_up(st.N, kTileN), padK = round_up(st.K, kPadK);
+    std::vector<int32_t> tb;
+    build_table(gb, 0, st.Bt, tb); st.t.obA = append(P.tables, tb);
+    build_table(gb, 1, st.Bt, tb); st.t.obB = append(P.tables, tb);
+    build_table(gb, 2, st.Bt, tb); st.t.obC = append(P.tables, tb);
+    build_table(gm, 0, padM, tb);  st.t.omA = append(P.tables, tb);
+    build_table(gm, 2, padM, tb);  st.t.omC = append(P.tables, tb);
+    build_table(gn, 1, padN, tb);  st.t.onB = append(P.tables, tb);
+    build_table(gn, 2, padN, tb);  st.t.onC = append(P.tables, tb);
+    build_table(gk, 0, padK, tb);  st.t.okA = append(P.tables, tb);
+    build_table(gk, 1, padK, tb);  st.t.okB = append(P.tables, tb);
+
+    // -- workspace: allocate the output, then release the consumed intermediates
+    if (!last) out.ws_offset = arena.alloc(out.numel * es);
+    for (int id : {lhs, rhs}) {
+      if (id >= d.n_inputs) arena.release(P.tensors[id].ws_offset, P.tensors[id].numel * es);
+    }
+    P.tensors.push_back(std::move(out));
+    P.steps.push_back(std::move(st));
+  }
+  for (int id = 0; id < d.n_inputs + d.n_steps - 1; ++id) {
+    if (!consumed[id]) { err = fmt("tensor %lld is never contracted: the path must reduce the network to one tensor", id); return CTN_INVALID_ARG; }
+  }
+  P.ws_bytes_per_replica = arena.top;
+  P.bytes_min += P.output().numel * es;
+  return CTN_OK;
+}
+
+}  // namespace ctn

@@ -1,0 +1,78 @@
+// plan.h - host-side lowering of a pairwise contraction DAG to kernel launches.
+//
+// Pure host code (no HIP): every step of the reference's contraction list
+// (reference contractn/einsum.py:341-391) is classified label by label into
+// batch / M / N / K groups, intermediates get a layout chosen for the consumer,
+// and gather-offset tables are built so the kernels never see strings, strides
+// or transposes (the reference's `_tensordot` + lazy `_transpose`,
+// einsum.py:371-377, collapse into table-driven loads/stores).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "ctn_abi.h"
+
+namespace ctn {
+
+constexpr int kMaxPartials = 64;   // abs-sum partial slots per (step, replica): one wave reduces them
+constexpr int kTileM = 128;        // MFMA f32 workgroup tile
+constexpr int kTileN = 128;
+constexpr int kTile64 = 64;        // MFMA f64 workgroup tile
+constexpr bool kEnableMfmaF64 = false;  // flipped once the f64 MFMA kernel lands
+constexpr int kPadK = 32;          // k-offset tables are padded to this multiple
+constexpr int64_t kAlign = 256;    // byte alignment of workspace tensors
+
+struct Tensor {
+  std::vector<int32_t> labels;
+  std::vector<int64_t> dims;
+  std::vector<int64_t> strides;  // in elements
+  int64_t numel = 1;
+  bool is_input = false;
+  int producer = -1;      // step that writes it (-1 for inputs)
+  int64_t ws_offset = -1; // byte offset inside one replica's workspace (intermediates)
+};
+
+// offsets (in int32 entries) of one step's tables inside Plan::tables
+struct TableRefs {
+  int64_t obA = 0, obB = 0, obC = 0, omA = 0, omC = 0, onB = 0, onC = 0, okA = 0, okB = 0;
+};
+
+struct Step {
+  int lhs = -1, rhs = -1, out = -1;  // tensor ids after the optional operand swap; rhs -1 = unary
+  bool swapped = false;
+  int kernel = CTN_KERNEL_ELEMENT;
+  int64_t Bt = 1, M = 1, N = 1, K = 1;
+  bool has_k = false;  // false: pure product (no summed label)
+  int modeA = 0, modeB = 0;
+  int blocks = 1;      // workgroups per replica
+  int partials = 1;    // partial abs-sums per replica after the optional collapse pass
+  bool collapse = false;
+  double flops = 0;
+  TableRefs t;
+};
+
+struct Plan {
+  int dtype = CTN_F32;
+  int n_inputs = 0;
+  int n_steps = 0;
+  bool stabilize = true;
+  double min_norm = 1e-7;
+  std::vector<Tensor> tensors;  // n_inputs inputs, then one per step
+  std::vector<Step> steps;
+  std::vector<int32_t> tables;
+  int64_t ws_bytes_per_replica = 0;
+  int64_t input_bytes_per_replica = 0;  // staging size when operands arrive as host pointers
+  std::vector<int64_t> input_offsets;   // byte offset of each input inside the staging block
+  int64_t max_collapse_blocks = 0;
+  double flops = 0;
+  int64_t bytes_min = 0;
+
+  size_t elem_size() const { return dtype == CTN_F64 ? 8 : 4; }
+  const Tensor& output() const { return tensors.back(); }
+};
+
+// Build a plan; on failure returns a negative ctn_status and fills `err`.
+int build_plan(const ctn_plan_desc& d, Plan& plan, std::string& err);
+
+}  // namespace ctn

@@ -1,0 +1,290 @@
+"""``contract()``: stabilised einsum dispatched to the MI355X engine.
+
+Host mirror of reference contractn/einsum.py with the same names, arguments and
+error behaviour:
+
+* ``make_einstring``   - reference einsum.py:117-130
+* ``make_arg_packer``  - reference einsum.py:133-187
+* ``contract``         - reference einsum.py:190-310 (kwargs, TypeError on unknown kwarg)
+* ``_contract_path``   - reference einsum.py:313-323 (lru-cached contraction list)
+* ``_core_contract``   - reference einsum.py:326-393: here it lowers the contraction
+  list to SSA form and hands it to the native plan/executor through the C ABI
+  (include/ctn_abi.h).  The pairwise loop, tensordot/transpose/einsum and
+  ``stabilize`` all run inside HIP kernels; nothing is computed on the CPU
+  except the final log accumulation of the per-step rescale factors (done in
+  the reference's order and precision so the log-scale register is
+  reproducible bit for bit when the abs-sums are exact) and ``destabilize``.
+
+There is no CPU fallback: without the HIP library or a GPU, ``contract`` raises.
+"""
+from functools import lru_cache
+
+import numpy as np
+
+from . import engine, paths
+
+MIN_NORM = 1e-7  # reference einsum.py:94
+_VALID_EINSUM_KWARGS = ("dtype", "order", "casting")
+
+
+# ---------------------------------------------------------------------------
+# compile step: TN -> einsum string / operand packer
+# ---------------------------------------------------------------------------
+def make_einstring(tn):
+    """Einsum string of a TN: dense/clone/input nodes in insertion order are the
+    operand terms (copy nodes are skipped - they only force shared symbols),
+    danglers in insertion order give the output."""
+    terms, free = [], []
+    for node in tn.nodes(as_iter=True, copy_nodes=False, danglers=True):
+        if node.dangler:
+            free.append(node.symbol)
+        else:
+            terms.append("".join(node.edge_symbols))
+    return ",".join(terms) + "->" + "".join(free)
+
+
+def make_arg_packer(tn):
+    """``(params, inputs) -> operand tuple`` for the TN's einsum string.
+
+    ``params`` are the unique dense tensors in node order; clone nodes reuse
+    their base node's slot; ``inputs`` fill the input nodes in node order.
+    """
+    slot_of_param = {}   # dense node name -> index in params
+    operand_src = []     # per operand: ("p", param index) or ("i", input index)
+    n_inputs = 0
+    for node in tn.nodes(as_iter=True, copy_nodes=False, danglers=False):
+        kind = node.node_type
+        if kind == "dense":
+            assert node.name not in slot_of_param
+            slot_of_param[node.name] = len(slot_of_param)
+            operand_src.append(("p", slot_of_param[node.name]))
+        elif kind == "clone":
+            base = node.base_node.name
+            assert base in slot_of_param, "clone node precedes its base node"
+            operand_src.append(("p", slot_of_param[base]))
+        elif kind == "input":
+            operand_src.append(("i", n_inputs))
+            n_inputs += 1
+        else:  # pragma: no cover
+            raise AssertionError(f"unexpected node type {kind}")
+    n_params = len(slot_of_param)
+
+    def arg_packer(params, inputs):
+        assert len(params) == n_params
+        assert len(inputs) == n_inputs
+        return tuple(params[j] if src == "p" else inputs[j] for src, j in operand_src)
+
+    return arg_packer
+
+
+# ---------------------------------------------------------------------------
+# planner: cached contraction list, cached native plan
+# ---------------------------------------------------------------------------
+@lru_cache()
+def _contract_path(einstr, operand_shapes, **kwargs):
+    """Cached contraction list in opt_einsum's ``einsum_call=True`` format."""
+    oe = paths.use_opt_einsum()
+    if oe is not None:
+        _, clist = oe.contract_path(einstr, *operand_shapes, shapes=True, einsum_call=True, **kwargs)
+        return tuple(clist)
+    return paths.contraction_list(einstr, operand_shapes, **kwargs)
+
+
+def lower_contraction_list(n_operands, contract_list):
+    """opt_einsum-style shrinking positions -> SSA steps with integer labels.
+
+    Returns ``(in_labels, steps)``; ``steps[k] = (lhs_id, rhs_id | -1, out_labels)``,
+    inputs are ids ``0..n-1`` and step ``k`` defines id ``n+k``.  The operand popped
+    from the higher position is the left one (reference einsum.py:344).
+    """
+    live = list(range(n_operands))
+    terms = {}
+    steps = []
+    for num, (inds, _idx_rm, step_str, _rest, _flag) in enumerate(contract_list):
+        ids = [live.pop(p) for p in inds]
+        lhs, out = step_str.split("->")
+        parts = lhs.split(",")
+        if len(parts) != len(ids) or len(ids) not in (1, 2):
+            raise NotImplementedError(
+                f"step {num}: only unary and pairwise contraction steps are supported"
+            )
+        for tid, term in zip(ids, parts):
+            if tid < n_operands:
+                terms.setdefault(tid, term)
+        new_id = n_operands + num
+        live.append(new_id)
+        steps.append((ids[0], ids[1] if len(ids) == 2 else -1, tuple(ord(c) for c in out)))
+    if len(live) != 1:
+        raise ValueError("contraction list does not reduce the operands to a single tensor")
+    missing = [i for i in range(n_operands) if i not in terms]
+    assert not missing, f"operands {missing} never contracted"
+    in_labels = [tuple(ord(c) for c in terms[i]) for i in range(n_operands)]
+    return in_labels, steps
+
+
+@lru_cache(maxsize=256)
+def _native_plan(contract_list, shapes, dtype_name):
+    in_labels, steps = lower_contraction_list(len(shapes), contract_list)
+    for lab, shp in zip(in_labels, shapes):
+        if len(lab) != len(shp):
+            raise ValueError(f"operand of shape {shp} does not match its {len(lab)} subscripts")
+    return engine.Plan(dtype_name, in_labels, shapes, steps, stabilize=True, min_norm=MIN_NORM)
+
+
+def _executor_for(plan, replicas=1):
+    cache = plan.__dict__.setdefault("_executors", {})
+    ex = cache.get(replicas)
+    if ex is None:
+        ex = cache[replicas] = engine.Executor(plan, replicas=replicas)
+    return ex
+
+
+# ---------------------------------------------------------------------------
+# scale register (host part of stabilize / destabilize)
+# ---------------------------------------------------------------------------
+def accumulate_log_scale(step_rescales, dtype):
+    """Sum of log(rescale) over the steps, in path order, with the reference's
+    NumPy semantics (reference einsum.py:104-106): ``log`` is
+    evaluated in the tensor dtype, the register is a float64 0-d array."""
+    resc = np.asarray(step_rescales, dtype=np.float64)
+    logs = np.zeros(resc.shape, dtype=np.float64)
+    mask = resc > 0
+    logs[mask] = np.log(resc[mask].astype(dtype)).astype(np.float64)
+    if logs.size == 0:
+        return np.zeros(())
+    return np.asarray(np.add.accumulate(logs)[-1])  # strictly sequential adds
+
+
+def destabilize(tensor, log_scale, backend="numpy"):
+    """``tensor * exp(log_scale)`` (reference einsum.py:110-114); may overflow to inf by design."""
+    if backend == "torch":
+        import torch
+
+        return tensor * torch.exp(log_scale)
+    return tensor * np.exp(log_scale)
+
+
+# ---------------------------------------------------------------------------
+# executor seam
+# ---------------------------------------------------------------------------
+def parse_backend(arrays, backend="auto"):
+    """Name of the array library of the operands ('numpy' or 'torch')."""
+    if backend not in (None, "auto"):
+        return backend
+    for a in arrays:
+        mod = type(a).__module__.split(".")[0]
+        if mod == "torch":
+            return "torch"
+    return "numpy"
+
+
+def _common_dtype(operands, backend, requested=None):
+    if requested is not None:
+        dt = np.dtype(requested)
+    elif backend == "torch":
+        import torch
+
+        dt = np.dtype(np.float64 if any(o.dtype == torch.float64 for o in operands) else np.float32)
+        if any(o.dtype.is_complex for o in operands):
+            raise NotImplementedError("complex tensors are not supported by the HIP engine")
+    else:
+        dt = np.result_type(*[np.asarray(o).dtype for o in operands])
+    if dt.kind == "c":
+        raise NotImplementedError("complex tensors are not supported by the HIP engine")
+    if dt == np.float32:
+        return np.dtype(np.float32)
+    if dt.kind == "f" and dt.itemsize < 4:
+        return np.dtype(np.float32)
+    return np.dtype(np.float64)  # ints, bools, float64 -> float64
+
+
+def _core_contract(operands, contract_list, backend="numpy", **einsum_kwargs):
+    """Run a contraction list on the GPU; returns ``(rescaled result, log_scale)``.
+
+    Same seam as reference einsum.py:326-393: ``contract_list`` is the list of
+    5-tuples produced by ``contract_path(..., einsum_call=True)``.
+    """
+    operands = list(operands)
+    contract_list = tuple(
+        (tuple(c[0]), frozenset(c[1]), c[2], None, c[4]) for c in contract_list
+    )
+    dtype = _common_dtype(operands, backend, einsum_kwargs.get("dtype"))
+    shapes = tuple(tuple(int(d) for d in op.shape) for op in operands)
+    plan = _native_plan(contract_list, shapes, dtype.name)
+    if backend == "torch":
+        return _run_torch(plan, operands, dtype)
+    ex = _executor_for(plan, 1)
+    outs, _dev_log, resc = ex.run_host([operands])
+    log_scale = accumulate_log_scale(resc[0], dtype)
+    return outs[0], log_scale
+
+
+def _run_torch(plan, operands, dtype):
+    import torch
+
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    if not all(o.is_cuda for o in operands):
+        ex = _executor_for(plan, 1)
+        host = [o.detach().cpu().numpy() for o in operands]
+        outs, _dev_log, resc = ex.run_host([host])
+        log_scale = accumulate_log_scale(resc[0], dtype)
+        return torch.from_numpy(outs[0]), torch.tensor(float(log_scale), dtype=tdt)
+    dev = operands[0].device
+    ops = [o.to(device=dev, dtype=tdt).contiguous() for o in operands]
+    out = torch.empty(plan.out_shape, dtype=tdt, device=dev)
+    cache = plan.__dict__.setdefault("_torch_executors", {})
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev.index or 0, stream)
+    ex = cache.get(key)
+    if ex is None:
+        ex = cache[key] = engine.Executor(plan, replicas=1, device=dev.index or 0, stream=stream)
+    ex.enqueue([o.data_ptr() for o in ops], [out.data_ptr()])
+    _dev_log, resc = ex.fetch()
+    log_scale = accumulate_log_scale(resc[0], dtype)
+    return out, torch.tensor(float(log_scale), dtype=tdt, device=dev)
+
+
+# ---------------------------------------------------------------------------
+# public entry point
+# ---------------------------------------------------------------------------
+def contract(*operands, **kwargs):
+    """Stabilised einsum: ``contract(subscripts, *operands, split_format=False,
+    optimize=True, use_blas=True, memory_limit=None, backend="auto", dtype=None,
+    order="K", casting="safe")``.
+
+    Drop-in for reference ``contractn.contract`` (einsum.py:190-310).  With
+    ``split_format=True`` returns ``(rescaled_output, log_scale)`` where
+    ``output == rescaled_output * exp(log_scale)``; otherwise the de-stabilised
+    product (which may overflow, as in the reference).
+    """
+    optimize_arg = kwargs.pop("optimize", True)
+    if optimize_arg is True:
+        optimize_arg = "auto"
+    elif not isinstance(optimize_arg, (str, bool)) and optimize_arg is not None:
+        optimize_arg = tuple(tuple(int(p) for p in step) for step in optimize_arg)  # hashable
+
+    einsum_kwargs = {k: v for k, v in kwargs.items() if k in _VALID_EINSUM_KWARGS}
+    use_blas = kwargs.pop("use_blas", True)
+    split_format = kwargs.pop("split_format", False)
+    memory_limit = kwargs.pop("memory_limit", None)
+    backend = kwargs.pop("backend", "auto")
+
+    unknown = [k for k in kwargs if k not in _VALID_EINSUM_KWARGS]
+    if unknown:
+        raise TypeError("Did not understand the following kwargs: {}".format(unknown))
+
+    assert isinstance(operands[0], str)
+    einstr, tensors = operands[0], operands[1:]
+    backend = parse_backend(tensors, backend)
+    if backend not in ("numpy", "torch"):
+        raise NotImplementedError(
+            f"backend '{backend}' is not supported: the MI355X engine takes numpy or torch tensors"
+        )
+    shapes = tuple(tuple(int(d) for d in op.shape) for op in tensors)
+    contract_list = _contract_path(
+        einstr, shapes, optimize=optimize_arg, memory_limit=memory_limit, use_blas=use_blas
+    )
+    result, log_scale = _core_contract(tensors, contract_list, backend, **einsum_kwargs)
+    if split_format:
+        return result, log_scale
+    return destabilize(result, log_scale, backend)

@@ -1,0 +1,311 @@
+"""ctypes binding of ``libctn_hip.so`` (include/ctn_abi.h) - the only way compute is reached.
+
+There is no CPU fallback: if the library is missing, or no gfx950 device is
+visible when a contraction is executed, a RuntimeError is raised.  Plans are
+pure host objects, so they can be built and inspected without a GPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libctn_hip.so")
+
+CTN_F32, CTN_F64 = 0, 1
+CTN_MEM_HOST, CTN_MEM_DEVICE = 0, 1
+KERNEL_NAMES = {0: "element", 1: "dot", 2: "mfma_f32", 3: "mfma_f64"}
+
+_STATUS_EXC = {
+    -1: AssertionError,
+    -2: ValueError,
+    -3: NotImplementedError,
+    -4: MemoryError,
+    -5: RuntimeError,
+    -6: RuntimeError,
+    -7: RuntimeError,
+}
+
+# every symbol include/ctn_abi.h declares
+ABI_SYMBOLS = (
+    "ctn_version", "ctn_last_error", "ctn_device_count",
+    "ctn_plan_create", "ctn_plan_destroy", "ctn_plan_dtype", "ctn_plan_n_inputs",
+    "ctn_plan_n_steps", "ctn_plan_flops", "ctn_plan_bytes_min", "ctn_plan_out_ndim",
+    "ctn_plan_out_dims", "ctn_plan_out_numel", "ctn_plan_out_bytes",
+    "ctn_plan_workspace_bytes", "ctn_plan_step_info",
+    "ctn_exec_create", "ctn_exec_destroy", "ctn_exec_run", "ctn_exec_enqueue",
+    "ctn_exec_fetch", "ctn_exec_synchronize", "ctn_exec_set_timing", "ctn_exec_step_ms",
+)
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("n_inputs", C.c_int32),
+        ("in_ndim", C.POINTER(C.c_int32)),
+        ("in_dims", C.POINTER(C.c_int64)),
+        ("in_labels", C.POINTER(C.c_int32)),
+        ("in_strides", C.POINTER(C.c_int64)),
+        ("n_steps", C.c_int32),
+        ("step_lhs", C.POINTER(C.c_int32)),
+        ("step_rhs", C.POINTER(C.c_int32)),
+        ("step_out_ndim", C.POINTER(C.c_int32)),
+        ("step_out_labels", C.POINTER(C.c_int32)),
+        ("stabilize", C.c_int32),
+        ("min_norm", C.c_double),
+    ]
+
+
+class StepInfo(C.Structure):
+    _fields_ = [
+        ("kernel", C.c_int32),
+        ("swapped", C.c_int32),
+        ("batch", C.c_int64),
+        ("m", C.c_int64),
+        ("n", C.c_int64),
+        ("k", C.c_int64),
+        ("mode_a", C.c_int32),
+        ("mode_b", C.c_int32),
+        ("partials", C.c_int32),
+        ("blocks", C.c_int32),
+        ("flops", C.c_double),
+        ("out_numel", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def load_library():
+    """Load the engine library (built by ``__graft_entry__.build()`` / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"HIP engine library not found at {LIB_PATH}; build it with "
+            "`make -C contractn_amd/csrc` (there is no CPU fallback)"
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    sig = {
+        "ctn_version": (i32, []),
+        "ctn_last_error": (C.c_char_p, []),
+        "ctn_device_count": (i32, [C.POINTER(C.c_int)]),
+        "ctn_plan_create": (i32, [C.POINTER(PlanDesc), C.POINTER(vp)]),
+        "ctn_plan_destroy": (None, [vp]),
+        "ctn_plan_dtype": (i32, [vp]),
+        "ctn_plan_n_inputs": (i32, [vp]),
+        "ctn_plan_n_steps": (i32, [vp]),
+        "ctn_plan_flops": (f64, [vp]),
+        "ctn_plan_bytes_min": (i64, [vp]),
+        "ctn_plan_out_ndim": (i32, [vp]),
+        "ctn_plan_out_dims": (i32, [vp, C.POINTER(C.c_int64)]),
+        "ctn_plan_out_numel": (i64, [vp]),
+        "ctn_plan_out_bytes": (i64, [vp]),
+        "ctn_plan_workspace_bytes": (i64, [vp, i32]),
+        "ctn_plan_step_info": (i32, [vp, i32, C.POINTER(StepInfo)]),
+        "ctn_exec_create": (i32, [vp, i32, vp, i32, C.POINTER(vp)]),
+        "ctn_exec_destroy": (None, [vp]),
+        "ctn_exec_run": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp), i32,
+                               C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "ctn_exec_enqueue": (i32, [vp, C.POINTER(vp), C.POINTER(vp)]),
+        "ctn_exec_fetch": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "ctn_exec_synchronize": (i32, [vp]),
+        "ctn_exec_set_timing": (i32, [vp, i32]),
+        "ctn_exec_step_ms": (i32, [vp, C.POINTER(C.c_float)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc < 0:
+        msg = load_library().ctn_last_error().decode("utf-8", "replace")
+        raise _STATUS_EXC.get(rc, RuntimeError)(f"ctn engine error {rc}: {msg}")
+    return rc
+
+
+def device_count():
+    """Number of visible HIP devices (0 when there is none)."""
+    n = C.c_int(0)
+    rc = load_library().ctn_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _i32(seq):
+    return np.ascontiguousarray(np.asarray(list(seq), dtype=np.int32))
+
+
+def _i64(seq):
+    return np.ascontiguousarray(np.asarray(list(seq), dtype=np.int64))
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class Plan:
+    """Immutable native plan for one (einsum string, shapes, path, dtype)."""
+
+    def __init__(self, dtype, in_labels, in_dims, steps, stabilize=True, min_norm=1e-7,
+                 in_strides=None):
+        """``in_labels``/``in_dims``: per-operand int lists; ``steps``: (lhs, rhs|-1, out_labels)."""
+        lib = load_library()
+        self.np_dtype = np.dtype(dtype)
+        if self.np_dtype == np.float32:
+            code = CTN_F32
+        elif self.np_dtype == np.float64:
+            code = CTN_F64
+        else:
+            raise TypeError(f"HIP engine supports float32/float64, got {self.np_dtype}")
+        ndim = _i32(len(lab) for lab in in_labels)
+        dims = _i64(d for shp in in_dims for d in shp)
+        labels = _i32(l for lab in in_labels for l in lab)
+        lhs = _i32(s[0] for s in steps)
+        rhs = _i32(s[1] for s in steps)
+        ond = _i32(len(s[2]) for s in steps)
+        olab = _i32(l for s in steps for l in s[2])
+        desc = PlanDesc()
+        desc.dtype = code
+        desc.n_inputs = len(in_labels)
+        desc.in_ndim = _ptr(ndim, C.c_int32)
+        desc.in_dims = _ptr(dims, C.c_int64)
+        desc.in_labels = _ptr(labels, C.c_int32)
+        if in_strides is not None:
+            strides = _i64(s for st in in_strides for s in st)
+            desc.in_strides = _ptr(strides, C.c_int64)
+        desc.n_steps = len(steps)
+        desc.step_lhs = _ptr(lhs, C.c_int32)
+        desc.step_rhs = _ptr(rhs, C.c_int32)
+        desc.step_out_ndim = _ptr(ond, C.c_int32)
+        desc.step_out_labels = _ptr(olab, C.c_int32)
+        desc.stabilize = 1 if stabilize else 0
+        desc.min_norm = float(min_norm)
+        handle = C.c_void_p()
+        _check(lib.ctn_plan_create(C.byref(desc), C.byref(handle)))
+        self._h = handle
+        self._lib = lib
+        self.n_inputs = len(in_labels)
+        self.n_steps = len(steps)
+        nd = lib.ctn_plan_out_ndim(handle)
+        od = (C.c_int64 * max(nd, 1))()
+        _check(lib.ctn_plan_out_dims(handle, od))
+        self.out_shape = tuple(int(od[i]) for i in range(nd))
+        self.flops = float(lib.ctn_plan_flops(handle))
+        self.bytes_min = int(lib.ctn_plan_bytes_min(handle))
+        self.out_bytes = int(lib.ctn_plan_out_bytes(handle))
+
+    def workspace_bytes(self, replicas=1):
+        return int(self._lib.ctn_plan_workspace_bytes(self._h, replicas))
+
+    def step_info(self, step):
+        info = StepInfo()
+        _check(self._lib.ctn_plan_step_info(self._h, step, C.byref(info)))
+        return {name: getattr(info, name) for name, _ in StepInfo._fields_}
+
+    def step_infos(self):
+        return [self.step_info(s) for s in range(self.n_steps)]
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ctn_plan_destroy(h)
+
+
+class Executor:
+    """Device state for ``replicas`` simultaneous contractions of one plan."""
+
+    def __init__(self, plan, replicas=1, device=0, stream=None):
+        lib = load_library()
+        if device_count() == 0:
+            raise RuntimeError(
+                "no HIP device visible: the contraction engine has no CPU fallback "
+                f"({lib.ctn_last_error().decode()})"
+            )
+        self.plan = plan
+        self.replicas = int(replicas)
+        self.device = int(device)
+        self._lib = lib
+        handle = C.c_void_p()
+        _check(lib.ctn_exec_create(plan._h, self.device, C.c_void_p(stream or 0), self.replicas,
+                                   C.byref(handle)))
+        self._h = handle
+        self._log = np.zeros(self.replicas, dtype=np.float64)
+        self._resc = np.zeros((self.replicas, plan.n_steps), dtype=np.float64)
+
+    # -- host (numpy) operands ------------------------------------------------
+    def run_host(self, operand_sets):
+        """``operand_sets``: list (len = replicas) of operand lists (C-contiguous numpy arrays).
+
+        Returns (outs [replicas, *out_shape], device log_scale [replicas], rescales [replicas, n_steps]).
+        """
+        plan, R = self.plan, self.replicas
+        assert len(operand_sets) == R
+        keep = []
+        ptrs = (C.c_void_p * (R * plan.n_inputs))()
+        for r, ops in enumerate(operand_sets):
+            assert len(ops) == plan.n_inputs
+            for i, op in enumerate(ops):
+                arr = np.ascontiguousarray(op, dtype=plan.np_dtype)
+                keep.append(arr)
+                ptrs[r * plan.n_inputs + i] = arr.ctypes.data
+        outs = np.empty((R,) + plan.out_shape, dtype=plan.np_dtype)
+        optrs = (C.c_void_p * R)()
+        stride = outs[0].nbytes if R else 0
+        for r in range(R):
+            optrs[r] = outs.ctypes.data + r * stride
+        _check(self._lib.ctn_exec_run(self._h, ptrs, CTN_MEM_HOST, optrs, CTN_MEM_HOST,
+                                      _ptr(self._log, C.c_double), _ptr(self._resc, C.c_double)))
+        return outs, self._log.copy(), self._resc.copy()
+
+    # -- device pointers --------------------------------------------------------
+    def enqueue(self, in_ptrs, out_ptrs):
+        """Asynchronous launch; ``in_ptrs``: replica-major flat list of device addresses."""
+        plan, R = self.plan, self.replicas
+        assert len(in_ptrs) == R * plan.n_inputs and len(out_ptrs) == R
+        ip = (C.c_void_p * len(in_ptrs))(*in_ptrs)
+        op = (C.c_void_p * R)(*out_ptrs)
+        _check(self._lib.ctn_exec_enqueue(self._h, ip, op))
+
+    def make_enqueue(self, in_ptrs, out_ptrs):
+        """Pre-marshal the pointer arrays once; returns a zero-argument launcher."""
+        plan, R = self.plan, self.replicas
+        assert len(in_ptrs) == R * plan.n_inputs and len(out_ptrs) == R
+        ip = (C.c_void_p * len(in_ptrs))(*in_ptrs)
+        op = (C.c_void_p * R)(*out_ptrs)
+        fn, h = self._lib.ctn_exec_enqueue, self._h
+
+        def launch():
+            rc = fn(h, ip, op)
+            if rc < 0:
+                _check(rc)
+
+        return launch
+
+    def fetch(self):
+        _check(self._lib.ctn_exec_fetch(self._h, _ptr(self._log, C.c_double),
+                                        _ptr(self._resc, C.c_double)))
+        return self._log.copy(), self._resc.copy()
+
+    def synchronize(self):
+        _check(self._lib.ctn_exec_synchronize(self._h))
+
+    def set_timing(self, enabled):
+        _check(self._lib.ctn_exec_set_timing(self._h, 1 if enabled else 0))
+
+    def step_ms(self):
+        ms = np.zeros(self.plan.n_steps, dtype=np.float32)
+        _check(self._lib.ctn_exec_step_ms(self._h, _ptr(ms, C.c_float)))
+        return ms
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ctn_exec_destroy(h)
+
+    def __del__(self):
+        self.close()

@@ -1,0 +1,157 @@
+/*
+ * ctn_abi.h - C ABI of the MI355X (gfx950) tensor-network contraction engine.
+ *
+ * This is the drop-in boundary for ContracTN's stabilised pairwise-contraction
+ * executor.  It replaces, for the one hot path:
+ *
+ *   reference contractn/einsum.py:326-393  _core_contract(operands, contract_list, backend)
+ *   reference contractn/einsum.py:89-107   stabilize()   (fused into every step's epilogue)
+ *   reference contractn/einsum.py:110-114  destabilize() (left to the host: one exp + multiply)
+ *   reference contractn/einsum.py:313-323  _contract_path() result -> ctn_plan (cached handle)
+ *
+ * A maintainer binds it with ctypes from contractn/einsum.py:303-305 (see
+ * INTEGRATION.md).  Strings never cross the boundary: einsum symbols are mapped
+ * to int32 labels, opt_einsum's shrinking operand positions to SSA tensor ids
+ * (inputs 0..n_inputs-1, step k defines id n_inputs+k; the operand popped from
+ * the HIGHER position is the step's lhs, reference einsum.py:344).
+ *
+ * Plain C types only.  No entry point throws or aborts; each returns CTN_OK or
+ * a negative ctn_status and leaves a message in ctn_last_error() (thread local).
+ *
+ * Threading: a ctn_plan is immutable after creation and may be shared between
+ * threads.  A ctn_exec owns mutable device state (workspace, pointer table,
+ * partial-sum buffers, stream) and must not be used by two threads at once;
+ * distinct ctn_exec objects may run concurrently.
+ */
+#ifndef CTN_ABI_H
+#define CTN_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTN_ABI_VERSION 1
+
+typedef enum {
+  CTN_OK = 0,
+  CTN_INVALID_ARG = -1,    /* -> TypeError / AssertionError on the Python side */
+  CTN_SHAPE_MISMATCH = -2, /* -> ValueError */
+  CTN_UNSUPPORTED = -3,    /* -> NotImplementedError */
+  CTN_OOM = -4,            /* -> MemoryError */
+  CTN_HIP_ERROR = -5,      /* -> RuntimeError */
+  CTN_RCCL_ERROR = -6,     /* reserved: collectives are issued by the host layer */
+  CTN_NO_DEVICE = -7       /* -> RuntimeError: no gfx950 device visible */
+} ctn_status;
+
+typedef enum { CTN_F32 = 0, CTN_F64 = 1 } ctn_dtype;
+
+/* where the caller's tensors live */
+typedef enum { CTN_MEM_HOST = 0, CTN_MEM_DEVICE = 1 } ctn_memspace;
+
+/* which kernel family a step was lowered to (ctn_step_info.kernel) */
+typedef enum {
+  CTN_KERNEL_ELEMENT = 0, /* one thread per output element, K loop (hyperedge / tiny steps) */
+  CTN_KERNEL_DOT = 1,     /* one workgroup per output element, K split over lanes */
+  CTN_KERNEL_MFMA_F32 = 2,/* 128x128 LDS-tiled v_mfma_f32_32x32x2_f32 GEMM, gather loads */
+  CTN_KERNEL_MFMA_F64 = 3 /* 64x64 LDS-tiled v_mfma_f64_16x16x4_f64 GEMM, gather loads */
+} ctn_kernel_kind;
+
+typedef struct ctn_plan ctn_plan;
+typedef struct ctn_exec ctn_exec;
+
+/*
+ * Description of one contraction DAG = what `_contract_path` returns in the
+ * reference (einsum.py:313-323) plus operand shapes, in integer form.
+ */
+typedef struct {
+  int32_t dtype;                  /* ctn_dtype */
+  int32_t n_inputs;
+  const int32_t* in_ndim;         /* [n_inputs] */
+  const int64_t* in_dims;         /* [sum in_ndim] extents, operand by operand */
+  const int32_t* in_labels;       /* [sum in_ndim] integer label of every axis */
+  const int64_t* in_strides;      /* [sum in_ndim] element strides, or NULL = C-contiguous */
+  int32_t n_steps;                /* >= 1 */
+  const int32_t* step_lhs;        /* [n_steps] SSA id of the left operand */
+  const int32_t* step_rhs;        /* [n_steps] SSA id of the right operand, -1 = unary step */
+  const int32_t* step_out_ndim;   /* [n_steps] */
+  const int32_t* step_out_labels; /* [sum step_out_ndim]; axis order is honoured for the LAST
+                                     step only - intermediates are laid out by the engine */
+  int32_t stabilize;              /* 1 = rescale after every step (reference einsum.py:387) */
+  double min_norm;                /* 1e-7 in the reference (einsum.py:94) */
+} ctn_plan_desc;
+
+typedef struct {
+  int32_t kernel;      /* ctn_kernel_kind */
+  int32_t swapped;     /* 1 if the engine exchanged lhs/rhs so that the output's unit-stride label is a column label */
+  int64_t batch;       /* |B|: labels shared by both operands and kept (hyperedge / batch) */
+  int64_t m, n, k;     /* |M|, |N| free extents, |K| contracted extent (incl. summed-out labels) */
+  int32_t mode_a;      /* 0 gather, 1 vector loads along the free index, 2 vector loads along k */
+  int32_t mode_b;
+  int32_t partials;    /* abs-sum partials per replica written by the step (<= 64) */
+  int32_t blocks;      /* workgroups per replica */
+  double flops;        /* 2*|B||M||N||K| (|B||M||N| when K is empty) + 3*numel(out) */
+  int64_t out_numel;
+} ctn_step_info;
+
+/* ---- library ---------------------------------------------------------- */
+int ctn_version(void);
+const char* ctn_last_error(void);
+/* number of visible HIP devices; CTN_NO_DEVICE if the runtime cannot be initialised */
+int ctn_device_count(int* count);
+
+/* ---- plan: pure host object, no HIP calls ----------------------------- */
+int ctn_plan_create(const ctn_plan_desc* desc, ctn_plan** out);
+void ctn_plan_destroy(ctn_plan* plan);
+int ctn_plan_dtype(const ctn_plan* plan);
+int ctn_plan_n_inputs(const ctn_plan* plan);
+int ctn_plan_n_steps(const ctn_plan* plan);
+/* algorithmic work of one contraction: sum over steps of ctn_step_info.flops */
+double ctn_plan_flops(const ctn_plan* plan);
+/* inputs read once + final output written once, in bytes */
+int64_t ctn_plan_bytes_min(const ctn_plan* plan);
+int ctn_plan_out_ndim(const ctn_plan* plan);
+int ctn_plan_out_dims(const ctn_plan* plan, int64_t* dims /* [out_ndim] */);
+int64_t ctn_plan_out_numel(const ctn_plan* plan);
+int64_t ctn_plan_out_bytes(const ctn_plan* plan);
+/* device bytes an executor for `replicas` simultaneous contractions will allocate */
+int64_t ctn_plan_workspace_bytes(const ctn_plan* plan, int replicas);
+int ctn_plan_step_info(const ctn_plan* plan, int step, ctn_step_info* info);
+
+/* ---- executor: device state for `replicas` independent contractions --- */
+/* stream: a hipStream_t, or NULL to let the executor create its own */
+int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas, ctn_exec** out);
+void ctn_exec_destroy(ctn_exec* exec);
+
+/*
+ * Synchronous contraction of `replicas` networks.
+ *   inputs  [replicas * n_inputs] operand pointers, replica-major; borrowed, never written
+ *   outs    [replicas] caller-allocated, ctn_plan_out_bytes() each, C-contiguous
+ *   log_scale      host [replicas]: sum over steps of log(rescale), accumulated on the device
+ *   step_rescales  host [replicas * n_steps] or NULL: the rescale factor of every step
+ *                  (0.0 where the step was not rescaled) so the caller can redo the
+ *                  log accumulation in the reference's exact order and precision
+ */
+int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space,
+                 void* const* outs, int outs_space, double* log_scale, double* step_rescales);
+
+/* Asynchronous variant: device pointers only, returns after enqueueing on the stream. */
+int ctn_exec_enqueue(ctn_exec* exec, const void* const* dev_inputs, void* const* dev_outs);
+/* Wait for the stream and copy out the scale registers of the last enqueue (either may be NULL). */
+int ctn_exec_fetch(ctn_exec* exec, double* log_scale, double* step_rescales);
+int ctn_exec_synchronize(ctn_exec* exec);
+
+/*
+ * Per-step device timing with HIP events recorded on the executor's stream.
+ * When enabled every step's kernels are bracketed by events; after a
+ * synchronize, ctn_exec_step_ms() returns the duration of each step of the
+ * most recent enqueue/run (ms[n_steps]).
+ */
+int ctn_exec_set_timing(ctn_exec* exec, int enabled);
+int ctn_exec_step_ms(ctn_exec* exec, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTN_ABI_H */
