@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Headline benchmark: contractions/s on <phi|psi> of two 100-site MPS (bond 256, phys 4, fp32).
+
+    python bench.py --gpus N --steps K --warmup W [--replicas R] [--sites 100 --bond 256 --phys 4]
+
+One "step" = one pass of the hot path (TN.contract's pairwise loop, stabilised,
+split format) over one batch of R independent synthetic networks whose tensors
+are already resident in HBM.  N>1: launched by torch.distributed.run, one rank
+per GPU; every rank contracts its own R networks (weak scaling, no data-path
+collective: replicas are independent - SURVEY.md 8e); timing is bracketed by a
+barrier + device synchronize and the MAX over ranks is reported.
+
+Rank 0 prints ONE JSON line (contract in the task statement) including
+  roofline     - dominant kernel (MFMA f32 GEMM) algorithmic flop / HIP-event duration vs 157.3 TFLOP/s
+  cpu_baseline - the NumPy oracle on the same network/path on this box's host cores (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--replicas", type=int, default=64, help="independent networks per step per GPU")
+    ap.add_argument("--sites", type=int, default=100)
+    ap.add_argument("--bond", type=int, default=256)
+    ap.add_argument("--phys", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-steps", default=None, help="write per-step kernel info + mean ms to this JSON file")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline time budget")
+    return ap.parse_args()
+
+
+def build_network(sites, bond, phys):
+    """Compile the TN once (front-end + path), exactly as TN.make_contract_fun would."""
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+
+    # tiny placeholder tensors are enough to build the graph; shapes are what matter
+    tn, ssa = nets.mps_overlap(TN, sites, bond, phys, dtype=np.float32, seed=3, scale=16.0)
+    path = ssa_to_linear(ssa, 2 * sites)
+    shapes = tuple(tuple(p.shape) for p in tn.params)
+    return tn, tn.einsum_str, shapes, path
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    from contractn_amd.einsum import BatchedContraction
+
+    R = args.replicas
+    tn, einstr, shapes, path = build_network(args.sites, args.bond, args.phys)
+    bc = BatchedContraction(einstr, shapes, np.float32, optimize=path, replicas=R, device=local_rank)
+    plan, ex = bc.plan, bc.executor
+    infos = plan.step_infos()
+
+    # synthetic inputs, resident in HBM: standard normal / 16, one seed per replica
+    gen = torch.Generator(device=dev)
+    numels = [int(np.prod(s)) for s in shapes]
+    offs = np.concatenate([[0], np.cumsum([(n + 63) // 64 * 64 for n in numels])])
+    flat = []
+    in_ptrs = []
+    for r in range(R):
+        gen.manual_seed(3 + r + 1000 * rank)
+        buf = torch.randn(int(offs[-1]), generator=gen, device=dev, dtype=torch.float32) / 16.0
+        flat.append(buf)
+        base = buf.data_ptr()
+        in_ptrs.extend(base + 4 * int(offs[i]) for i in range(len(shapes)))
+    out = torch.zeros(R, max(1, int(np.prod(plan.out_shape))), device=dev, dtype=torch.float32)
+    out_ptrs = [out[r].data_ptr() for r in range(R)]
+    launch = ex.make_enqueue(in_ptrs, out_ptrs)
+
+    def sync_all():
+        ex.synchronize()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        launch()
+    sync_all()
+
+    # ---- timed region: exactly K steps --------------------------------------------------
+    ex.set_timing(args.steps)  # HIP events around every step's kernels, on the executor's stream
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        launch()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    step_ms_last = ex.step_ms().astype(np.float64)  # per-step mean over the K timed passes
+    ex.set_timing(0)
+    logs = bc.fetch_log_scale()
+    t_hat = out[:, 0].cpu().numpy()
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    total_contractions = R * args.steps * world
+    value = total_contractions / elapsed
+    flops_per = plan.flops
+    tflops = value * flops_per / 1e12
+
+    if args.dump_steps and rank == 0:
+        with open(args.dump_steps, "w") as fh:
+            json.dump([dict(info, ms=float(step_ms_last[s])) for s, info in enumerate(infos)], fh)
+
+    # ---- roofline of the dominant kernel (per launch, HIP-event durations) ---------------
+    by_kernel = {}
+    for s, info in enumerate(infos):
+        key = (info["kernel"], info["mode_a"], info["mode_b"])
+        d = by_kernel.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
+        d["ms"] += step_ms_last[s]
+        d["flops"] += info["flops"] * R
+        d["launches"] += 1
+    dom_key = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
+    dom = by_kernel[dom_key]
+    from contractn_amd.engine import KERNEL_NAMES
+
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    mfma_ms = sum(d["ms"] for k, d in by_kernel.items() if k[0] == 2)
+    mfma_flops = sum(d["flops"] for k, d in by_kernel.items() if k[0] == 2)
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "mfma",
+        "kernel": f"k_{KERNEL_NAMES[dom_key[0]]}<modeA={dom_key[1]},modeB={dom_key[2]}>",
+        "achieved": round(achieved, 3),
+        "peak": PEAK_F32_MFMA_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        "traffic": traffic,
+        "launches_per_step": dom["launches"],
+        "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
+        "flop_per_launch": dom["flops"] / max(dom["launches"], 1),
+        "all_mfma_launches_tflops": round(mfma_flops / (mfma_ms * 1e-3) / 1e12, 3) if mfma_ms > 0 else None,
+        "end_to_end_tflops": round(tflops / world, 3),
+        "end_to_end_frac": round(tflops / world / PEAK_F32_MFMA_TFLOPS, 4),
+    }
+
+    result = {
+        "metric": "contractions/sec (MPS-100 overlap, bond=256, phys=4, fp32, stabilised split format)",
+        "value": round(value, 2),
+        "unit": "contractions/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (standard normal / 16, on-device generator, seeds 3+replica)",
+        "config": {
+            "workload": f"mps_overlap_{args.sites}sites_D{args.bond}_d{args.phys}_zipper_R{R}",
+            "replicas_per_gpu": R,
+            "steps_per_contraction": plan.n_steps,
+            "flop_per_contraction": flops_per,
+            "bytes_min_per_contraction": plan.bytes_min,
+            "parallelism": f"replicas x{world}",
+        },
+        "achieved_tflops": round(tflops, 3),
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline: the oracle on the same network and path (rank 0, N=1 only) --------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(einstr, shapes, path, flat[0], offs, numels, args.cpu_seconds,
+                                              float(t_hat[0]), float(logs[0]))
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(einstr, shapes, path, flat0, offs, numels, budget_s, gpu_t, gpu_c):
+    """Time the NumPy oracle (oracle/cpu_ref.py, kind 'port') on replica 0's tensors."""
+    from oracle import cpu_ref
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max((p.get("num_threads", 1) for p in threadpool_info()), default=1)
+    except Exception:
+        threads = os.cpu_count()
+    host = flat0.cpu().numpy()
+    ops = [host[int(offs[i]): int(offs[i]) + numels[i]].reshape(shapes[i]) for i in range(len(shapes))]
+    clist = cpu_ref.contraction_list(einstr, shapes, path)
+    t_ref, c_ref, _ = cpu_ref.core_contract(ops, clist)  # warm-up + parity sample
+    n, t0 = 0, time.perf_counter()
+    while True:
+        cpu_ref.core_contract(ops, clist)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 50:
+            break
+    ok = abs(gpu_t - float(t_ref)) <= 1e-3 and abs(gpu_c - float(c_ref)) <= 1e-3 * max(1.0, abs(float(c_ref)))
+    return {
+        "value": round(n / dt, 3),
+        "unit": "contractions/s",
+        "cores": int(threads),
+        "host_cpus": os.cpu_count(),
+        "kind": "port",
+        "sample": f"{n} full contractions of replica 0 (same 100-site network, same zipper path, "
+                  f"NumPy/OpenBLAS) in {dt:.1f}s",
+        "parity_vs_gpu": {"ok": bool(ok), "gpu": [gpu_t, gpu_c], "cpu": [float(t_ref), float(c_ref)]},
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -207,37 +207,45 @@ __global__ __launch_bounds__(256) void k_finalize(FinalArgs f) {
 
 // ---------------------------------------------------------------------------
 // K-mfma-f32: 128x128 workgroup tile, 4 waves (2x2), each wave 64x64 =
-// 2x2 v_mfma_f32_32x32x2_f32 accumulators, BK=16, register-staged double-buffered LDS.
+// 2x2 v_mfma_f32_32x32x2_f32 accumulators, register-staged double-buffered LDS,
+// one barrier per k-tile.
 //
 // MODE (per operand): 0 scalar gather, 1 float4 along the free index (LDS image
-// [k][m]), 2 float4 along k (LDS image [m][k+1], odd row length => conflict-free
+// [k][m]), 2 float4 along k (LDS image [m][BK+1], odd row length => conflict-free
 // ds_read_b32 for the MFMA fragment: lane l reads row l&31, k = 2*kk + (l>>5)).
+//
+// Latency structure: the k-offset table entries of tile t+2 are requested while
+// tile t+1's data loads are in flight and tile t is being multiplied, so no
+// load ever waits on a table lookup; global loads are unconditional (padded
+// tables keep every address in bounds) and masked with a select; LDS fragment
+// reads run one k-step ahead of the MFMAs that consume them.
 // ---------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = kTileM, BN = kTileN, BK = 16;
+constexpr int BM = kTileM, BN = kTileN;
 
-template <int MODE>
+template <int MODE, int BK>
 struct TileLoader {
-  // registers holding one 128 x BK operand tile slice of this thread (8 floats)
-  float v[8];
-  int offm[MODE == 0 ? 1 : 2];  // hoisted free-index offsets
-  bool okm[MODE == 0 ? 1 : 2];
+  static constexpr int NV = BM * BK / 256;                 // floats staged per thread
+  static constexpr int NT = MODE == 1 ? NV / 4 : (MODE == 2 ? 1 : NV);   // table entries per tile
+  static constexpr int NM = MODE == 2 ? NV / 4 : 1;        // hoisted free-index offsets
+  static constexpr int LDK = BK + 1;
+  static constexpr int kSize = MODE == 2 ? BM * LDK : BK * BM;
 
-  __device__ __forceinline__ void init(const int32_t* om, int m0, int M, int tid) {
+  float v[NV];
+  int kofs[NT];   // k-offset table entries of the NEXT tile to load
+  int offm[NM];
+  bool okm[NM];
+
+  __device__ __forceinline__ void init(const int32_t* __restrict__ om, int m0, int M, int tid) {
     if (MODE == 1) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int f = tid + i * 256;
-        const int gm = m0 + (f & 31) * 4;
-        offm[i] = om[gm];
-        okm[i] = gm < M;
-      }
+      const int gm = m0 + (tid & 31) * 4;
+      offm[0] = om[gm];
+      okm[0] = gm < M;
     } else if (MODE == 2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int f = tid + i * 256;
-        const int gm = m0 + (f >> 2);
+      for (int i = 0; i < NM; ++i) {
+        const int gm = m0 + ((tid + i * 256) / (BK / 4));
         offm[i] = om[gm];
         okm[i] = gm < M;
       }
@@ -248,74 +256,156 @@ struct TileLoader {
     }
   }
 
-  __device__ __forceinline__ void load(const float* __restrict__ base, const int32_t* __restrict__ ok,
-                                       int k0, int K, int tid) {
+  // request the table entries this thread needs for the tile starting at k0 (table is padded)
+  __device__ __forceinline__ void tab(const int32_t* __restrict__ ok, int k0, int tid) {
     if (MODE == 1) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int f = tid + i * 256;
-        const int gk = k0 + (f >> 5);
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (okm[i] && gk < K) x = *reinterpret_cast<const float4*>(base + offm[i] + ok[gk]);
-        v[4 * i + 0] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
-      }
+      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + (tid >> 5) + 8 * i];
     } else if (MODE == 2) {
-      const int gk = k0 + (tid & 3) * 4;
-      const bool kin = gk < K;
-      const int offk = ok[gk];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (okm[i] && kin) x = *reinterpret_cast<const float4*>(base + offm[i] + offk);
-        v[4 * i + 0] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
-      }
+      kofs[0] = ok[k0 + (tid % (BK / 4)) * 4];
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int gk = k0 + (tid >> 7) + 2 * i;
-        float x = 0.f;
-        if (okm[0] && gk < K) x = base[offm[0] + ok[gk]];
-        v[i] = x;
-      }
+      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + (tid >> 7) + 2 * i];
     }
   }
 
-  __device__ __forceinline__ void store(float* __restrict__ s, int tid) const {
+  // issue the global loads of the tile using the entries fetched by the previous tab().
+  // Unconditional: padded tables keep every address inside the tensor; out-of-range rows and
+  // k are zeroed later, in store(), so nothing here waits on the data.
+  __device__ __forceinline__ void load(const float* __restrict__ base) {
     if (MODE == 1) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int f = tid + i * 256;
-        *reinterpret_cast<float4*>(s + (f >> 5) * BM + (f & 31) * 4) =
-            make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+      for (int i = 0; i < NT; ++i) {
+        const float4 x = *reinterpret_cast<const float4*>(base + offm[0] + kofs[i]);
+        v[4 * i + 0] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
       }
     } else if (MODE == 2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int f = tid + i * 256;
-        float* d = s + (f >> 2) * (BK + 1) + (f & 3) * 4;
-        d[0] = v[4 * i]; d[1] = v[4 * i + 1]; d[2] = v[4 * i + 2]; d[3] = v[4 * i + 3];
+      for (int i = 0; i < NM; ++i) {
+        const float4 x = *reinterpret_cast<const float4*>(base + offm[i] + kofs[0]);
+        v[4 * i + 0] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s[((tid >> 7) + 2 * i) * BM + (tid & 127)] = v[i];
+      for (int i = 0; i < NT; ++i) v[i] = base[offm[0] + kofs[i]];
+    }
+  }
+
+  // write the staged tile (loaded from k0) into its LDS image; FULL skips the bounds masks
+  template <bool FULL>
+  __device__ __forceinline__ void store(float* __restrict__ s, int k0, int K, int tid) const {
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const bool in = FULL || (okm[0] && (k0 + (tid >> 5) + 8 * i) < K);
+        *reinterpret_cast<float4*>(s + ((tid >> 5) + 8 * i) * BM + (tid & 31) * 4) =
+            make_float4(in ? v[4 * i] : 0.f, in ? v[4 * i + 1] : 0.f, in ? v[4 * i + 2] : 0.f,
+                        in ? v[4 * i + 3] : 0.f);
+      }
+    } else if (MODE == 2) {
+      const bool kin = (k0 + (tid % (BK / 4)) * 4) < K;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const bool in = FULL || (okm[i] && kin);
+        float* d = s + ((tid + i * 256) / (BK / 4)) * LDK + (tid % (BK / 4)) * 4;
+        d[0] = in ? v[4 * i] : 0.f; d[1] = in ? v[4 * i + 1] : 0.f;
+        d[2] = in ? v[4 * i + 2] : 0.f; d[3] = in ? v[4 * i + 3] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const bool in = FULL || (okm[0] && (k0 + (tid >> 7) + 2 * i) < K);
+        s[((tid >> 7) + 2 * i) * BM + (tid & 127)] = in ? v[i] : 0.f;
+      }
     }
   }
 
   // LDS index of element (row, k) of the tile image
   static __device__ __forceinline__ int idx(int row, int k) {
-    return MODE == 2 ? row * (BK + 1) + k : k * BM + row;
+    return MODE == 2 ? row * LDK + k : k * BM + row;
   }
-  static constexpr int kSize = MODE == 2 ? BM * (BK + 1) : BK * BM;
 };
 
-template <int MA, int MB>
+template <int MA, int MB, int BK, bool FULL>
+__device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK>& la, TileLoader<MB, BK>& lb,
+                                              const float* __restrict__ A, const float* __restrict__ B,
+                                              const int32_t* __restrict__ okA, const int32_t* __restrict__ okB,
+                                              int K, float* sA, float* sB, f32x16 (&acc)[2][2], int tid) {
+  using LA = TileLoader<MA, BK>;
+  using LB = TileLoader<MB, BK>;
+  constexpr int SZA = LA::kSize, SZB = LB::kSize;
+  const int lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int nkt = (K + BK - 1) / BK;
+  la.tab(okA, 0, tid);
+  lb.tab(okB, 0, tid);
+  la.load(A);
+  lb.load(B);
+  la.tab(okA, BK, tid);
+  lb.tab(okB, BK, tid);
+  la.template store<FULL>(sA, 0, K, tid);
+  lb.template store<FULL>(sB, 0, K, tid);
+  __syncthreads();
+
+  // per-lane LDS fragment bases (element indices)
+  const int fa0 = LA::idx(wm + l31, h), fa1 = LA::idx(wm + 32 + l31, h);
+  const int fb0 = LB::idx(wn + l31, h), fb1 = LB::idx(wn + 32 + l31, h);
+  constexpr int stepA = MA == 2 ? 2 : 2 * BM;  // advance of the fragment index per k-step (k += 2)
+  constexpr int stepB = MB == 2 ? 2 : 2 * BN;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      la.load(A);
+      lb.load(B);
+      la.tab(okA, (kt + 2) * BK, tid);
+      lb.tab(okB, (kt + 2) * BK, tid);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // global loads stay in front of the MFMA phase
+    const float* cA = sA + cur * SZA;
+    const float* cB = sB + cur * SZB;
+    float fa[2][2], fb[2][2];
+    fa[0][0] = cA[fa0]; fa[0][1] = cA[fa1];
+    fb[0][0] = cB[fb0]; fb[0][1] = cB[fb1];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int c = kk & 1, nx = c ^ 1;
+      if (kk + 1 < BK / 2) {
+        fa[nx][0] = cA[fa0 + (kk + 1) * stepA]; fa[nx][1] = cA[fa1 + (kk + 1) * stepA];
+        fb[nx][0] = cB[fb0 + (kk + 1) * stepB]; fb[nx][1] = cB[fb1 + (kk + 1) * stepB];
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
+      // pin the interleave: the LDS reads of step kk+1 issue ahead of the MFMAs of step kk
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the staged tile is consumed only after the MFMA phase
+    if (more) {
+      la.template store<FULL>(sA + (cur ^ 1) * SZA, (kt + 1) * BK, K, tid);
+      lb.template store<FULL>(sB + (cur ^ 1) * SZB, (kt + 1) * BK, K, tid);
+    }
+    __syncthreads();
+  }
+}
+
+template <int MA, int MB, int BK>
 __global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
-  constexpr int SZA = TileLoader<MA>::kSize, SZB = TileLoader<MB>::kSize;
-  __shared__ __attribute__((aligned(16))) float smem[2 * SZA + 2 * SZB + 4];
-  __shared__ int s_omC[BM], s_onC[BN];
-  __shared__ double red[4];
+  using LA = TileLoader<MA, BK>;
+  using LB = TileLoader<MB, BK>;
+  constexpr int SZA = LA::kSize, SZB = LB::kSize;
+  // one LDS object: [A buf0][A buf1][B buf0][B buf1][omC 128][onC 128][red 4 doubles]
+  __shared__ __attribute__((aligned(16))) float smem[2 * SZA + 2 * SZB + BM + BN + 8];
   float* sA = smem;
   float* sB = smem + 2 * SZA;
+  int* s_omC = reinterpret_cast<int*>(smem + 2 * SZA + 2 * SZB);
+  int* s_onC = s_omC + BM;
+  double* red = reinterpret_cast<double*>(s_onC + BN);
 
   const int tid = threadIdx.x;
   // XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs, so give each
@@ -342,8 +432,8 @@ __global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
   if (tid < BM) s_omC[tid] = a.omC[m0 + tid];
   else s_onC[tid - BM] = a.onC[n0 + tid - BM];
 
-  TileLoader<MA> la;
-  TileLoader<MB> lb;
+  LA la;
+  LB lb;
   la.init(a.omA, m0, a.M, tid);
   lb.init(a.onB, n0, a.N, tid);
 
@@ -359,40 +449,10 @@ __global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nkt = (a.K + BK - 1) / BK;
-  la.load(A, a.okA, 0, a.K, tid);
-  lb.load(B, a.okB, 0, a.K, tid);
-  la.store(sA, tid);
-  lb.store(sB, tid);
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nkt;
-    if (more) {
-      la.load(A, a.okA, (kt + 1) * BK, a.K, tid);
-      lb.load(B, a.okB, (kt + 1) * BK, a.K, tid);
-    }
-    const float* cA = sA + cur * SZA;
-    const float* cB = sB + cur * SZB;
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const int k = kk * 2 + h;
-      const float a0 = cA[TileLoader<MA>::idx(wm + l31, k)];
-      const float a1 = cA[TileLoader<MA>::idx(wm + 32 + l31, k)];
-      const float b0 = cB[TileLoader<MB>::idx(wn + l31, k)];
-      const float b1 = cB[TileLoader<MB>::idx(wn + 32 + l31, k)];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (more) {
-      la.store(sA + (cur ^ 1) * SZA, tid);
-      lb.store(sB + (cur ^ 1) * SZB, tid);
-    }
-    __syncthreads();
-  }
+  // FULL: the tile lies completely inside M x N and K is a multiple of BK -> no masking
+  const bool full = (m0 + BM <= a.M) && (n0 + BN <= a.N) && (a.K % BK == 0);
+  if (full) mfma_mainloop<MA, MB, BK, true>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid);
+  else mfma_mainloop<MA, MB, BK, false>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid);
 
   // epilogue: lazy rescale, store through the C offset tables, abs-sum partial
   const float iA = 1.0f / scA, iB = 1.0f / scB;
@@ -454,9 +514,9 @@ struct Exec {
   double* d_stepNumel = nullptr;
   char* d_stage_in = nullptr;
   char* d_stage_out = nullptr;
-  bool timing = false;
-  std::vector<hipEvent_t> events;  // 2 per step
-  bool events_recorded = false;
+  int timing_slots = 0;             // 0 = timing off
+  int timing_runs = 0;              // enqueues recorded since timing was enabled
+  std::vector<hipEvent_t> events;   // [slot][step][2]
 
   ~Exec() {
     (void)hipSetDevice(device);
@@ -469,21 +529,36 @@ struct Exec {
   }
 };
 
-template <int MA>
+template <int MA, int BK>
 static void launch_mfma_b(int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
   switch (mb) {
-    case 1: hipLaunchKernelGGL((k_mfma_f32<MA, 1>), grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((k_mfma_f32<MA, 2>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((k_mfma_f32<MA, 0>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((k_mfma_f32<MA, 1, BK>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_mfma_f32<MA, 2, BK>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_mfma_f32<MA, 0, BK>), grid, dim3(256), 0, st, a); break;
   }
 }
 
-static void launch_mfma(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
+template <int BK>
+static void launch_mfma_a(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
   switch (ma) {
-    case 1: launch_mfma_b<1>(mb, grid, st, a); break;
-    case 2: launch_mfma_b<2>(mb, grid, st, a); break;
-    default: launch_mfma_b<0>(mb, grid, st, a); break;
+    case 1: launch_mfma_b<1, BK>(mb, grid, st, a); break;
+    case 2: launch_mfma_b<2, BK>(mb, grid, st, a); break;
+    default: launch_mfma_b<0, BK>(mb, grid, st, a); break;
   }
+}
+
+// tuning knob (development only): CTN_MFMA_BK=16|32 selects the k-tile depth
+static int mfma_bk() {
+  static int bk = [] {
+    const char* e = getenv("CTN_MFMA_BK");
+    return (e && atoi(e) == 16) ? 16 : 32;
+  }();
+  return bk;
+}
+
+static void launch_mfma(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
+  if (mfma_bk() == 16) launch_mfma_a<16>(ma, mb, grid, st, a);
+  else launch_mfma_a<32>(ma, mb, grid, st, a);
 }
 
 static int exec_launch_all(Exec* E) {
@@ -521,7 +596,8 @@ static int exec_launch_all(Exec* E) {
     a.blocks_per_replica = st.blocks;
     a.R = R;
 
-    if (E->timing) HIPCHECK(hipEventRecord(E->events[2 * s], E->stream));
+    const size_t ev0 = E->timing_slots ? ((size_t)(E->timing_runs % E->timing_slots) * P.n_steps + s) * 2 : 0;
+    if (E->timing_slots) HIPCHECK(hipEventRecord(E->events[ev0], E->stream));
     switch (st.kernel) {
       case CTN_KERNEL_MFMA_F32: {
         const int64_t total = (int64_t)st.blocks * R;
@@ -540,7 +616,7 @@ static int exec_launch_all(Exec* E) {
     }
     if (st.collapse)
       hipLaunchKernelGGL(k_collapse, dim3(R), dim3(256), 0, E->stream, (const double*)E->d_scratch, st.blocks, part_dst);
-    if (E->timing) HIPCHECK(hipEventRecord(E->events[2 * s + 1], E->stream));
+    if (E->timing_slots) HIPCHECK(hipEventRecord(E->events[ev0 + 1], E->stream));
   }
   FinalArgs f;
   f.ptrs = E->d_ptrs;
@@ -558,7 +634,7 @@ static int exec_launch_all(Exec* E) {
   if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_finalize<float>, dim3(fb, R), dim3(256), 0, E->stream, f);
   else hipLaunchKernelGGL(k_finalize<double>, dim3(fb, R), dim3(256), 0, E->stream, f);
   HIPCHECK(hipGetLastError());
-  E->events_recorded = E->timing;
+  if (E->timing_slots) E->timing_runs++;
   return CTN_OK;
 }
 
@@ -576,7 +652,7 @@ static int exec_set_pointers(Exec* E, const void* const* dev_inputs, void* const
     }
     void* o = dev_outs[r];
     if (!o) { g_err = "null output pointer"; return CTN_INVALID_ARG; }
-    if ((uintptr_t)o % 16) { g_err = "output pointers must be 16-byte aligned"; return CTN_INVALID_ARG; }
+    if ((uintptr_t)o % P.elem_size()) { g_err = "output pointers must be element aligned"; return CTN_INVALID_ARG; }
     const int id_out = P.n_inputs + P.n_steps - 1;
     if (row[id_out] != o) { row[id_out] = o; changed = true; }
   }
@@ -819,26 +895,39 @@ int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space, vo
   return ctn_exec_fetch(exec, log_scale, step_rescales);
 }
 
-int ctn_exec_set_timing(ctn_exec* exec, int enabled) {
-  if (!exec) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+int ctn_exec_set_timing(ctn_exec* exec, int slots) {
+  if (!exec || slots < 0) { g_err = "invalid argument"; return CTN_INVALID_ARG; }
   Exec* E = &exec->e;
   HIPCHECK(hipSetDevice(E->device));
-  if (enabled && E->events.empty()) {
-    E->events.resize((size_t)2 * E->plan->n_steps);
-    for (auto& ev : E->events) HIPCHECK(hipEventCreate(&ev));
+  HIPCHECK(hipStreamSynchronize(E->stream));
+  const size_t need = (size_t)slots * E->plan->n_steps * 2;
+  while (E->events.size() < need) {
+    hipEvent_t ev;
+    HIPCHECK(hipEventCreate(&ev));
+    E->events.push_back(ev);
   }
-  E->timing = enabled != 0;
-  if (!E->timing) E->events_recorded = false;
+  E->timing_slots = slots;
+  E->timing_runs = 0;
   return CTN_OK;
 }
 
 int ctn_exec_step_ms(ctn_exec* exec, float* ms) {
   if (!exec || !ms) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
   Exec* E = &exec->e;
-  if (!E->events_recorded) { g_err = "no timed run recorded: call ctn_exec_set_timing(1) then enqueue"; return CTN_INVALID_ARG; }
+  const int used = std::min(E->timing_runs, E->timing_slots);
+  if (used < 1) { g_err = "no timed run recorded: call ctn_exec_set_timing(slots) then enqueue"; return CTN_INVALID_ARG; }
   HIPCHECK(hipStreamSynchronize(E->stream));
-  for (int s = 0; s < E->plan->n_steps; ++s)
-    HIPCHECK(hipEventElapsedTime(&ms[s], E->events[2 * s], E->events[2 * s + 1]));
+  const int ns = E->plan->n_steps;
+  for (int s = 0; s < ns; ++s) {
+    double acc = 0;
+    for (int slot = 0; slot < used; ++slot) {
+      float t = 0;
+      const size_t ev0 = ((size_t)slot * ns + s) * 2;
+      HIPCHECK(hipEventElapsedTime(&t, E->events[ev0], E->events[ev0 + 1]));
+      acc += t;
+    }
+    ms[s] = (float)(acc / used);
+  }
   return CTN_OK;
 }
 

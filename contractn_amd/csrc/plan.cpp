@@ -315,7 +315,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     // -- gather-offset tables
     std::vector<const LabelInfo*> gb(G[kBatch].begin(), G[kBatch].end()), gm(G[kM].begin(), G[kM].end()),
         gn(G[kN].begin(), G[kN].end()), gk(G[kK].begin(), G[kK].end());
-    const int64_t padM = round_up(st.M, kTileM), padN = round_up(st.N, kTileN), padK = round_up(st.K, kPadK);
+    const int64_t padM = round_up(st.M, kTileM), padN = round_up(st.N, kTileN), padK = round_up(st.K, kPadK) + 2 * kPadK;  // kernels prefetch table entries two tiles ahead
     std::vector<int32_t> tb;
     build_table(gb, 0, st.Bt, tb); st.t.obA = append(P.tables, tb);
     build_table(gb, 1, st.Bt, tb); st.t.obB = append(P.tables, tb);

@@ -288,3 +288,42 @@ def contract(*operands, **kwargs):
     if split_format:
         return result, log_scale
     return destabilize(result, log_scale, backend)
+
+
+# ---------------------------------------------------------------------------
+# throughput API: R independent contractions of one network per launch sequence
+# ---------------------------------------------------------------------------
+class BatchedContraction:
+    """``replicas`` independent contractions of one compiled network in flight at once.
+
+    A single contraction of a dependent chain cannot fill 256 CUs (SURVEY.md H1);
+    this is the grouped form: every pairwise step is ONE kernel launch covering
+    all replicas.  Operands are device pointers (``enqueue``) or NumPy arrays
+    (``run_host``).  Results: ``(t_hat [R, ...], log_scale [R])`` in split format.
+    """
+
+    def __init__(self, einstr, shapes, dtype, optimize="auto", replicas=1, device=0, stream=None,
+                 memory_limit=None, use_blas=True):
+        if not isinstance(optimize, (str, bool)) and optimize is not None:
+            optimize = tuple(tuple(int(p) for p in step) for step in optimize)
+        shapes = tuple(tuple(int(d) for d in s) for s in shapes)
+        self.einsum_str = einstr
+        self.dtype = np.dtype(dtype)
+        self.contract_list = _contract_path(einstr, shapes, optimize=optimize,
+                                            memory_limit=memory_limit, use_blas=use_blas)
+        self.plan = _native_plan(self.contract_list, shapes, self.dtype.name)
+        self.replicas = int(replicas)
+        self.executor = engine.Executor(self.plan, replicas=self.replicas, device=device, stream=stream)
+
+    def run_host(self, operand_sets):
+        outs, _dev_log, resc = self.executor.run_host(operand_sets)
+        logs = np.array([accumulate_log_scale(resc[r], self.dtype) for r in range(self.replicas)])
+        return outs, logs
+
+    def enqueue(self, in_ptrs, out_ptrs):
+        self.executor.enqueue(in_ptrs, out_ptrs)
+
+    def fetch_log_scale(self):
+        """Wait for the last enqueue; log-scale registers accumulated in the reference's order."""
+        _dev_log, resc = self.executor.fetch()
+        return np.array([accumulate_log_scale(resc[r], self.dtype) for r in range(self.replicas)])

@@ -294,8 +294,9 @@ class Executor:
     def synchronize(self):
         _check(self._lib.ctn_exec_synchronize(self._h))
 
-    def set_timing(self, enabled):
-        _check(self._lib.ctn_exec_set_timing(self._h, 1 if enabled else 0))
+    def set_timing(self, slots):
+        """Bracket every step of the next ``slots`` enqueues with HIP events (0 = off)."""
+        _check(self._lib.ctn_exec_set_timing(self._h, int(slots)))
 
     def step_ms(self):
         ms = np.zeros(self.plan.n_steps, dtype=np.float32)

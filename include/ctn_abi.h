@@ -144,11 +144,13 @@ int ctn_exec_synchronize(ctn_exec* exec);
 
 /*
  * Per-step device timing with HIP events recorded on the executor's stream.
- * When enabled every step's kernels are bracketed by events; after a
- * synchronize, ctn_exec_step_ms() returns the duration of each step of the
- * most recent enqueue/run (ms[n_steps]).
+ * ctn_exec_set_timing(exec, slots): slots > 0 brackets every step's kernels of
+ * the next `slots` enqueues with events (further enqueues reuse the slots
+ * round-robin); 0 switches timing off.  ctn_exec_step_ms() waits for the
+ * stream and returns, per step, the mean duration over the recorded enqueues
+ * (ms[n_steps]).
  */
-int ctn_exec_set_timing(ctn_exec* exec, int enabled);
+int ctn_exec_set_timing(ctn_exec* exec, int slots);
 int ctn_exec_step_ms(ctn_exec* exec, float* ms);
 
 #ifdef __cplusplus
