@@ -1,0 +1,150 @@
+"""Multi-GPU execution of the contraction path: one process per GPU, RCCL over xGMI.
+
+The reference has no distributed layer at all.  The path
+shards in two ways:
+
+* **replicas** - independent networks (same plan, different tensors) are dealt
+  round-robin to the ranks; there is NO data-path collective
+  (:func:`shard_range`; this is what ``bench.py --gpus N`` does);
+* **index slicing** - one network, a set S of contracted labels is fixed to each
+  of its joint values in turn; every slice is an independent contraction with
+  the same plan on sliced operands, slices are dealt to the ranks, each rank
+  combines its partial results locally in split format and the join is ONE
+  ``all_gather`` of ``(T_hat_g, c_g)`` (a scalar PEPS amplitude: 4-8 B + 8 B per
+  GPU - latency bound over xGMI, so a single collective and no ring) followed
+  by a local log-sum-exp combine.
+
+``torch.distributed`` is plumbing only (backend "nccl" == RCCL on ROCm; "gloo"
+in the CPU tests).  The per-slice compute goes through ``contract`` (HIP engine)
+unless a different ``contract_fn`` is injected (the CPU tests inject the oracle).
+"""
+import itertools
+
+import numpy as np
+
+from . import paths
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced share of ``range(n_items)`` for ``rank``."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def combine_split(parts):
+    """Sum tensors given in split format ``[(T_hat, c), ...]`` without leaving it.
+
+    ``sum_g T_hat_g * exp(c_g) = exp(c*) * sum_g T_hat_g * exp(c_g - c*)`` with
+    ``c* = max c_g``; the result is re-stabilised (mean |T| == 1) exactly like a
+    contraction step (reference einsum.py:89-107).
+    """
+    parts = [(np.asarray(t), float(c)) for t, c in parts]
+    live = [(t, c) for t, c in parts if np.any(t != 0)]
+    if not live:
+        return parts[0][0] * 0, np.zeros(())
+    c_star = max(c for _, c in live)
+    total = sum(t.astype(np.float64) * np.exp(c - c_star) for t, c in live)
+    norm = np.sum(np.abs(total))
+    if norm > 1e-7:
+        rescale = norm / total.size
+        total = total / rescale
+        c_star = c_star + np.log(rescale)
+    return total.astype(parts[0][0].dtype), np.asarray(c_star, dtype=np.float64)
+
+
+def slice_network(einstr, operands, slice_labels):
+    """Yield ``(index tuple, sliced einsum string, sliced operands)`` for every joint
+    value of ``slice_labels`` (labels must be contracted, i.e. absent from the output)."""
+    shapes = [np.shape(o) for o in operands]
+    terms, out, sizes = paths.parse_einsum_input(einstr, shapes)
+    for lab in slice_labels:
+        if lab in out:
+            raise ValueError(f"cannot slice over output label '{lab}'")
+        if lab not in sizes:
+            raise ValueError(f"label '{lab}' is not in the network")
+    new_terms = ["".join(s for s in t if s not in slice_labels) for t in terms]
+    sliced_str = ",".join(new_terms) + "->" + out
+    ranges = [range(sizes[lab]) for lab in slice_labels]
+    for values in itertools.product(*ranges):
+        fix = dict(zip(slice_labels, values))
+        ops = []
+        for t, op in zip(terms, operands):
+            idx = tuple(fix[s] if s in fix else slice(None) for s in t)
+            ops.append(np.ascontiguousarray(np.asarray(op)[idx]))
+        yield values, sliced_str, ops
+
+
+def n_slices(einstr, operands, slice_labels):
+    shapes = [np.shape(o) for o in operands]
+    _, _, sizes = paths.parse_einsum_input(einstr, shapes)
+    n = 1
+    for lab in slice_labels:
+        n *= sizes[lab]
+    return n
+
+
+def contract_sliced(einstr, operands, slice_labels, optimize="auto", contract_fn=None,
+                    group=None, rank=None, world=None):
+    """Sliced contraction across the ranks of ``group``; returns ``(T_hat, log_scale)`` on every rank.
+
+    With ``world == 1`` (or torch.distributed not initialised) all slices run
+    locally and no collective is issued.
+    """
+    if contract_fn is None:
+        from .einsum import contract as contract_fn
+    dist = None
+    if world is None or rank is None:
+        try:
+            import torch.distributed as dist_mod
+
+            if dist_mod.is_available() and dist_mod.is_initialized():
+                dist = dist_mod
+                world = dist.get_world_size(group)
+                rank = dist.get_rank(group)
+        except ImportError:
+            pass
+    if world is None:
+        world, rank = 1, 0
+
+    total = n_slices(einstr, operands, slice_labels)
+    mine = set(shard_range(total, rank, world))
+    local = []
+    sliced_path = None
+    for num, (_vals, sliced_str, ops) in enumerate(slice_network(einstr, operands, slice_labels)):
+        if num not in mine:
+            continue
+        if sliced_path is None:
+            sliced_path = optimize
+        local.append(contract_fn(sliced_str, *ops, optimize=sliced_path, split_format=True))
+    out_shape = None
+    if local:
+        t_loc, c_loc = combine_split(local)
+        out_shape = t_loc.shape
+    else:  # more ranks than slices: contribute an exact zero
+        shapes = [np.shape(o) for o in operands]
+        _, out, sizes = paths.parse_einsum_input(einstr, shapes)
+        out_shape = tuple(sizes[s] for s in out)
+        t_loc, c_loc = np.zeros(out_shape, dtype=np.result_type(*[np.asarray(o).dtype for o in operands])), np.zeros(())
+    if world == 1:
+        return t_loc, c_loc
+    return all_gather_combine(t_loc, c_loc, group=group, world=world)
+
+
+def all_gather_combine(t_loc, c_loc, group=None, world=None):
+    """THE join: one all_gather of the packed ``(T_hat, c)`` buffers, then a local combine."""
+    import torch
+    import torch.distributed as dist
+
+    world = world or dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    flat = np.concatenate([np.asarray(t_loc, dtype=np.float64).ravel(), [float(c_loc)]])
+    send = torch.from_numpy(flat).to(device)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    parts = []
+    for buf in recv:
+        arr = buf.cpu().numpy()
+        parts.append((arr[:-1].reshape(np.shape(t_loc)).astype(np.asarray(t_loc).dtype), arr[-1]))
+    return combine_split(parts)

@@ -1,0 +1,134 @@
+"""C-ABI library: loads, exports every symbol of include/ctn_abi.h, plans build and validate on the host."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from contractn_amd import einsum as E
+from contractn_amd import engine
+from tests.helpers import ROOT, load_golden
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "ctn_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ctn_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = engine.load_library()
+    declared = header_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in ctn_abi.h but not exported"
+    assert sorted(engine.ABI_SYMBOLS) == declared
+    assert lib.ctn_version() == 1
+
+
+def test_library_has_no_torch_dependency():
+    import subprocess
+
+    out = subprocess.run(["ldd", engine.LIB_PATH], capture_output=True, text=True).stdout
+    assert "torch" not in out and "libamdhip64" in out
+
+
+def _plan(einstr, shapes, path, dtype="float32"):
+    clist = E._contract_path(einstr, tuple(shapes), optimize=path, memory_limit=None, use_blas=True)
+    return E._native_plan(clist, tuple(shapes), dtype)
+
+
+def test_plan_for_headline_network_lowers_to_mfma_gemms():
+    """Config 3a shape (reduced site count): every bulk step is an MFMA GEMM with vector loads."""
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+
+    tn, ssa = nets.mps_overlap(TN, 5, 256, 4, dtype=np.float32)
+    shapes = [p.shape for p in tn.params]
+    plan = _plan(tn.einsum_str, shapes, ssa_to_linear(ssa, 10))
+    infos = plan.step_infos()
+    assert plan.n_steps == 9 and plan.out_shape == ()
+    mfma = [i for i in infos if i["kernel"] == 2]
+    assert len(mfma) == 6
+    assert {(i["m"], i["n"], i["k"]) for i in mfma} == {(256, 1024, 256), (256, 256, 1024)}
+    assert all(i["mode_a"] in (1, 2) and i["mode_b"] in (1, 2) for i in mfma)
+    assert all(i["partials"] <= 64 for i in infos)
+    # flop count: 2*M*N*K + 3*numel(out) per step
+    assert mfma[0]["flops"] == 2.0 * mfma[0]["m"] * mfma[0]["n"] * mfma[0]["k"] + 3.0 * mfma[0]["out_numel"]
+    assert plan.flops == pytest.approx(sum(i["flops"] for i in infos))
+    assert plan.bytes_min == sum(int(np.prod(s)) for s in shapes) * 4 + 4
+    assert plan.workspace_bytes(8) > 8 * (256 * 1024 * 4)
+
+
+def test_headline_flop_count_matches_survey():
+    """100 sites, D=256, d=4: 98*4*d*D^3 + 2*2dD^2 + 2dD = 26,307,725,312 multiply-adds*2."""
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+
+    tn, ssa = nets.mps_overlap(TN, 100, 8, 4, dtype=np.float32)  # small bond: same structure
+    plan = _plan(tn.einsum_str, [p.shape for p in tn.params], ssa_to_linear(ssa, 200))
+    d, D = 4, 8
+    gemm = 98 * 4 * d * D ** 3 + 2 * 2 * d * D ** 2 + 2 * d * D
+    stab = 3 * sum(i["out_numel"] for i in plan.step_infos())
+    assert plan.n_steps == 199
+    assert plan.flops == gemm + stab
+
+
+def test_hyperedge_steps_have_batch_labels_and_no_delta_tensor():
+    g = load_golden("readme_copy101")
+    plan = _plan(g["einsum_str"], [o.shape for o in g["operands"]], g["path"], "float64")
+    infos = plan.step_infos()
+    assert len(infos) == 99
+    assert all(i["batch"] == 2 and i["m"] == i["n"] == i["k"] == 1 and i["kernel"] == 0 for i in infos)
+    assert plan.bytes_min == 100 * 2 * 8 + 2 * 8  # only the vectors and the output: no identity tensor
+
+
+def test_trace_sumout_and_unary_steps_lower():
+    plan = _plan("aa->", [(3, 3)], ((0,),), "float64")
+    i = plan.step_info(0)
+    assert (i["batch"], i["m"], i["n"], i["k"]) == (1, 1, 1, 3)
+    plan = _plan("ab->ab", [(2, 3)], ((0,),), "float64")
+    assert plan.out_shape == (2, 3)
+    plan = _plan("abc,cd->abd", [(4, 3, 5), (5, 2)], ((0, 1),), "float64")
+    assert plan.out_shape == (4, 3, 2)
+
+
+@pytest.mark.parametrize("bad,exc", [
+    (dict(in_dims=[(2, 3), (4, 2)]), ValueError),            # label extent mismatch
+    (dict(steps=[(0, 1, (ord("z"),))]), AssertionError),     # output label in neither operand
+    (dict(steps=[(0, 0, (ord("a"),))]), AssertionError),     # operand used twice
+    (dict(steps=[(0, 5, (ord("a"),))]), AssertionError),     # id out of range
+])
+def test_plan_validation_errors(bad, exc):
+    args = dict(in_labels=[(ord("a"), ord("b")), (ord("b"), ord("c"))], in_dims=[(2, 3), (3, 2)],
+                steps=[(0, 1, (ord("a"), ord("c")))])
+    args.update(bad)
+    with pytest.raises(exc):
+        engine.Plan("float32", args["in_labels"], args["in_dims"], args["steps"])
+
+
+def test_unsupported_dtype_rejected():
+    with pytest.raises(TypeError):
+        engine.Plan("complex64", [(1,)], [(2,)], [(0, -1, (1,))])
+
+
+def test_no_cpu_fallback_without_device():
+    if engine.device_count() > 0:
+        pytest.skip("a GPU is present")
+    plan = _plan("ab,bc->ac", [(2, 3), (3, 2)], ((0, 1),))
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        engine.Executor(plan)
+    from contractn_amd import contract
+
+    with pytest.raises(RuntimeError):
+        contract("ab,bc->ac", np.ones((2, 3), np.float32), np.ones((3, 2), np.float32))
+
+
+def test_raw_ctypes_error_reporting():
+    lib = engine.load_library()
+    handle = ctypes.c_void_p()
+    rc = lib.ctn_plan_create(None, ctypes.byref(handle))
+    assert rc == -1 and b"NULL" in lib.ctn_last_error()

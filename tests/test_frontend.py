@@ -1,0 +1,254 @@
+"""Front-end (TN / Node / Edge) behaviour: same einsum strings as the reference, same bookkeeping.
+
+Assertions modelled on reference contractn/tests/test_nodes.py and test_ctn.py; the golden
+fixtures carry the einsum strings the REFERENCE front-end produced for tests/networks.py.
+"""
+from itertools import combinations
+
+import numpy as np
+import pytest
+
+from contractn_amd import TN, Edge, Node
+from contractn_amd.utils import get_new_symbols, get_symbol, symbol_idx
+from tests import networks as nets
+from tests.helpers import load_golden
+
+
+def index_inverse_ok(tn):
+    for node in tn.nodes():
+        assert all(node.index(node[i]) == i for i in range(node.ndim))
+        assert all(node[node.index(e)].name == e for e in node.edge_names)
+
+
+# ---- einsum strings identical to the reference ---------------------------------
+def test_readme_strings():
+    cp, tucker = TN(), TN()
+    hub = cp.add_copy_node(3)
+    thub = tucker.add_dense_node(np.ones((4, 4, 4)))
+    for i in range(3):
+        mat = np.eye(4, 10)
+        cp.connect_nodes(hub, cp.add_dense_node(mat), i, 0)
+        tucker.connect_nodes(thub, tucker.add_dense_node(mat), i, 0)
+    assert cp.einsum_str == "ac,ad,ae->cde"          # README.md:56
+    assert tucker.einsum_str == "abc,ae,bf,cg->efg"  # README.md:57
+
+
+@pytest.mark.parametrize("name,builder", [
+    ("mps_overlap_6x8x3_f64", lambda: nets.mps_overlap(TN, 6, 8, 3, dtype=np.float64)[0]),
+    ("mps_open_random_f64", lambda: nets.mps_open(TN, (3, 5, 4), (2, 3, 2, 4))),
+    ("cp_r5_f64", lambda: nets.cp_network(TN, 5, (6, 7, 8))),
+    ("tucker_r5_f64", lambda: nets.tucker_network(TN, (5, 5, 5), (6, 7, 8))),
+    ("peps3x3_D2_f64", lambda: nets.peps_closed(TN, 3, 3, 2, dtype=np.float64, seed=7)),
+    ("peps3x4_D3_f64", lambda: nets.peps_closed(TN, 3, 4, 3, dtype=np.float64, seed=6)),
+    ("batched_mps_f64", lambda: nets.batched_mps(TN, 5, 6, 3, 7, dtype=np.float64)[0]),
+])
+def test_einsum_str_matches_reference_frontend(name, builder):
+    assert builder().einsum_str == load_golden(name)["einsum_str"]
+
+
+def test_chain_uses_unicode_symbols_like_reference():
+    tn = TN()
+    prev = tn.add_dense_node(np.ones(3))
+    for _ in range(1000):
+        mat = tn.add_dense_node(np.ones((3, 3)))
+        tn.connect_nodes(prev, mat, -1, 0)
+        prev = mat
+    assert tn.einsum_str == load_golden("readme_chain1000")["einsum_str"]
+    assert max(map(ord, tn.einsum_str)) == 1141
+
+
+def test_params_match_reference_operand_order():
+    g = load_golden("mps_overlap_6x8x3_f64")
+    tn, _ = nets.mps_overlap(TN, 6, 8, 3, dtype=np.float64)
+    for mine, ref in zip(tn.params, g["operands"]):
+        np.testing.assert_array_equal(mine, ref)
+
+
+# ---- symbols -------------------------------------------------------------------
+def test_symbol_table_roundtrip():
+    assert [get_symbol(i) for i in (0, 25, 26, 51)] == ["a", "z", "A", "Z"]
+    assert get_symbol(52) == chr(192)
+    for i in (0, 7, 51, 52, 53, 1000):
+        assert symbol_idx(get_symbol(i)) == i
+
+
+def test_gap_filling_allocator():
+    assert get_new_symbols(set(), 3) == ("a", "b", "c")
+    assert get_new_symbols({"a", "c", "e"}, 3) == ("b", "d", "f")
+    assert get_new_symbols({"b"}, 1) == ("a",)
+
+
+# ---- nodes (reference tests/test_nodes.py) --------------------------------------
+@pytest.mark.parametrize("order", range(4))
+def test_add_dense_node(order):
+    tn = TN()
+    tensor = np.ones((2,) * order)
+    node = tn.add_dense_node(tensor)
+    assert node.node_type == "dense" and node.name == "node_0"
+    assert tn.num_dense == tn.num_cores == 1 and tn.num_copy == tn.num_input == tn.num_duplicate == 0
+    assert tn.edge_symbols == set("abc"[:order])
+    assert all(n.dangler for n in node.neighbors)
+    assert node.ndim == order and node.shape == tensor.shape
+    assert node.edge_symbols == tuple("abc"[:order])
+    assert node.size == node.numel == tensor.size
+    index_inverse_ok(tn)
+    for attr in ("base_node", "degree", "dim", "var_axes"):
+        with pytest.raises(Exception):
+            getattr(node, attr)
+    with pytest.raises(TypeError):
+        tn.add_dense_node(tensor, name="node_0")
+
+
+@pytest.mark.parametrize("order", range(4))
+def test_add_duplicate_node(order):
+    tn = TN()
+    tensor = np.ones((2,) * order)
+    dense = tn.add_dense_node(tensor)
+    node = tn.add_duplicate_node(dense.name if order % 2 else dense)
+    assert node.node_type == "clone" and node.name == "node_1"
+    assert node.base_node is dense and node.shape == tensor.shape
+    assert node.size == tensor.size and node.numel == 0
+    assert node.edge_symbols == tuple("abcdef"[order:2 * order])
+    assert tn.num_dense == tn.num_duplicate == 1 and tn.num_cores == 2
+
+
+@pytest.mark.parametrize("order", range(4))
+@pytest.mark.parametrize("dim", [None, 5])
+def test_add_copy_node(order, dim):
+    tn = TN()
+    if order == 0:
+        with pytest.raises(Exception):
+            tn.add_copy_node(order, dim=dim)
+        return
+    node = tn.add_copy_node(order, dim=dim)
+    assert node.node_type == "hyper" and node.is_copy
+    assert node.edge_symbols == ("a",) * order and tn.edge_symbols == {"a"}
+    assert node.shape == ((-1 if dim is None else dim),) * order
+    assert node.size == (None if dim is None else dim ** order) and node.numel == 0
+    assert tn.num_copy == tn.num_cores == 1
+    other = TN().add_copy_node(order, edge_symbols="z")
+    assert other.edge_symbols == ("z",) * order
+    for attr in ("tensor", "base_node", "var_axes"):
+        with pytest.raises(Exception):
+            getattr(node, attr)
+
+
+def test_add_input_node():
+    tn = TN()
+    node = tn.add_input_node((4, 3, 2), var_shape_axes=(1,))
+    assert node.node_type == "input" and node.shape == (4, -1, 2)
+    assert node.size is None and node.numel == 0 and node.var_axes == (1,)
+    assert tn.num_input == 1
+    fixed = tn.add_input_node((4, 3))
+    assert fixed.size == 12
+
+
+# ---- edges (reference tests/test_ctn.py) ----------------------------------------
+@pytest.mark.parametrize("node_type", ["dense", "hyper"])
+@pytest.mark.parametrize("num_nodes", [2, 4, 6])
+@pytest.mark.parametrize("neg", [False, True])
+def test_connect_path(node_type, num_nodes, neg):
+    tn = TN()
+    make = (lambda: tn.add_dense_node(np.ones((3, 2, 2)))) if node_type == "dense" else (
+        lambda: tn.add_copy_node(3, dim=2))
+    nodes = [make() for _ in range(num_nodes)]
+    for i in range(num_nodes - 1):
+        tn.connect_nodes(nodes[i], nodes[i + 1], *((-1, -2) if neg else (2, 1)))
+    assert len(tn.nodes()) == tn.num_cores == num_nodes
+    assert len(tn.nodes(danglers=True)) == 2 * num_nodes + 2
+    assert len(tn.edges()) == 2 * num_nodes + 1
+    assert len(tn.edge_symbols) == (2 * num_nodes + 1 if node_type == "dense" else 1)
+    for i, node in enumerate(nodes):
+        nbrs = set(node.neighbors)
+        expect = set(nodes[max(i - 1, 0):i] + nodes[i + 1:i + 2])
+        assert expect.issubset(nbrs)
+        assert len(nbrs - expect) == 1 + int(i in (0, num_nodes - 1))
+    before = tn.einsum_str
+    tn._cleanup_edge_symbols()
+    assert tn.einsum_str == before
+    index_inverse_ok(tn)
+
+
+@pytest.mark.parametrize("node_type", ["dense", "hyper"])
+@pytest.mark.parametrize("num_nodes", [2, 3, 5])
+def test_connect_complete(node_type, num_nodes):
+    tn = TN()
+    if node_type == "dense":
+        nodes = [tn.add_dense_node(np.ones((3,) + (2,) * (num_nodes - 1))) for _ in range(num_nodes)]
+    else:
+        nodes = [tn.add_copy_node(num_nodes, dim=2) for _ in range(num_nodes)]
+    for i, j in combinations(range(num_nodes), 2):
+        tn.connect_nodes(nodes[i], nodes[j], j, i + 1)
+    assert len(tn.edges()) == (num_nodes ** 2 + num_nodes) // 2
+    assert len(tn.nodes(danglers=True)) == 2 * num_nodes
+    assert len(tn.edge_symbols) == ((num_nodes ** 2 + num_nodes) // 2 if node_type == "dense" else 1)
+    index_inverse_ok(tn)
+
+
+@pytest.mark.parametrize("num_nodes", [2, 4])
+@pytest.mark.parametrize("single", [False, True])
+@pytest.mark.parametrize("by_name", [False, True])
+def test_remove_edges(num_nodes, single, by_name):
+    tn = TN()
+    nodes = [tn.add_dense_node(np.ones((2,) * (num_nodes - 1))) for _ in range(num_nodes)]
+    for i, j in combinations(range(num_nodes), 2):
+        tn.connect_nodes(nodes[i], nodes[j], j - 1, i)
+    if single:
+        for e in tn.edges():
+            tn.remove_edge(e.name if by_name else e)
+    else:
+        tn.remove_edges_from([e.name for e in tn.edges()] if by_name else tn.edges())
+    assert tn.num_dense == tn.num_cores == num_nodes
+    assert len(tn.edges()) == len(tn.edge_symbols) == num_nodes * (num_nodes - 1)
+    assert all(e.dangler for e in tn.edges())
+
+
+def test_mismatched_dims_rejected():
+    tn = TN()
+    a, b = tn.add_dense_node(np.ones((2, 3))), tn.add_dense_node(np.ones((4, 2)))
+    with pytest.raises(AssertionError):
+        tn.connect_nodes(a, b, 1, 0)
+
+
+def test_connect_by_name_and_edge_objects():
+    tn = TN()
+    a, b = tn.add_dense_node(np.ones((2, 3)), name="A"), tn.add_dense_node(np.ones((3, 2)), name="B")
+    tn.connect_nodes("A", "B", 1, 0)  # reference ctn.py:184 crashes here
+    assert tn.einsum_str == "ab,bd->ad"
+    e = a[1]
+    assert isinstance(e, Edge) and isinstance(a, Node)
+    assert e.symbol == "b" and e.dim == 3 and not e.dangler and set(e.nodes) == {a, b}
+    assert a[0].dangler and a[0].var_dim is False
+
+
+# ---- copy-tensor handling (deliberate fixes) ---------------------
+def test_dense_before_copy_shares_one_symbol():
+    tn = TN()
+    vecs = [tn.add_dense_node(np.array([1.0, 2.0])) for _ in range(3)]
+    hub = tn.add_copy_node(4)
+    for i, v in enumerate(vecs):
+        tn.connect_nodes(hub, v, i, 0)
+    terms, out = tn.einsum_str.split("->")
+    assert len(set(terms.replace(",", ""))) == 1 and out == terms[0]
+
+
+def test_copy_copy_chain_merges_symbols():
+    tn = TN()
+    hubs = [tn.add_copy_node(3, dim=2) for _ in range(3)]
+    vec = tn.add_dense_node(np.ones(2))
+    tn.connect_nodes(hubs[0], hubs[1], 0, 0)
+    tn.connect_nodes(hubs[1], hubs[2], 1, 0)
+    tn.connect_nodes(hubs[2], vec, 1, 0)
+    assert len(tn.edge_symbols) == 1
+
+
+def test_clone_nodes_pack_base_tensor():
+    from contractn_amd.einsum import make_arg_packer
+
+    tn = TN()
+    base = tn.add_dense_node(np.arange(6.0).reshape(2, 3))
+    clone = tn.add_duplicate_node(base)
+    tn.connect_nodes(base, clone, 1, 1)
+    ops = make_arg_packer(tn)(tn.params, ())
+    assert len(ops) == 2 and ops[0] is ops[1]
+    assert tn.einsum_str == "ab,cb->ac"
