@@ -46,6 +46,7 @@ struct StepArgs {
   int32_t tiles_m, tiles_n;
   int32_t blocks_per_replica;
   int32_t R;
+  int32_t c_vec;  // float4 stores of C allowed
 };
 
 struct FinalArgs {
@@ -175,31 +176,40 @@ __global__ __launch_bounds__(256) void k_collapse(const double* scratch, int blo
 }
 
 // ---------------------------------------------------------------------------
-// Finishing pass: normalise the final tensor, accumulate the log-scale
-// register (reference einsum.py:103-106) and dump every step's rescale factor.
+// Finishing passes.  k_scales: one wave per (step, replica) turns the step's partials into its
+// rescale factor (0.0 = not rescaled) and log(rescale) evaluated in the tensor dtype
+// (reference einsum.py:97-106).  k_finalize: normalise the final tensor and sum the logs.
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_finalize(FinalArgs f) {
+__global__ __launch_bounds__(256) void k_scales(FinalArgs f, double* __restrict__ logs) {
   const int r = blockIdx.y;
-  const int last = f.n_steps - 1;
-  T s_last = (T)1;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= f.n_steps) return;  // whole wave exits together
+  bool cond = false;
+  T sc = (T)1;
   if (f.stabilize)
-    s_last = producer_scale<T>(f.partials + (size_t)last * f.R * kMaxPartials, f.stepP[last],
-                               f.stepNumel[last], f.min_norm, r);
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
-    double ls = 0;
-    for (int s = 0; s < f.n_steps; ++s) {
-      bool cond = false;
-      T sc = (T)1;
-      if (f.stabilize)
-        sc = producer_scale<T>(f.partials + (size_t)s * f.R * kMaxPartials, f.stepP[s], f.stepNumel[s],
-                               f.min_norm, r, &cond);
-      if (cond) ls += (double)log(sc);
-      if (threadIdx.x == 0) f.rescales[(size_t)r * f.n_steps + s] = cond ? (double)sc : 0.0;
-    }
-    if (threadIdx.x == 0) f.log_scale[r] = ls;
+    sc = producer_scale<T>(f.partials + (size_t)s * f.R * kMaxPartials, f.stepP[s], f.stepNumel[s],
+                           f.min_norm, r, &cond);
+  if ((threadIdx.x & 63) == 0) {
+    f.rescales[(size_t)r * f.n_steps + s] = cond ? (double)sc : 0.0;
+    logs[(size_t)r * f.n_steps + s] = cond ? (double)log(sc) : 0.0;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_finalize(FinalArgs f, const double* __restrict__ logs) {
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  if (blockIdx.x == 0) {
+    double v = 0;
+    for (int s = threadIdx.x; s < f.n_steps; s += 256) v += logs[(size_t)r * f.n_steps + s];
+    const double tot = block_sum(v, red);
+    if (threadIdx.x == 0) f.log_scale[r] = tot;
   }
   if (!f.stabilize) return;
+  const double rl = f.rescales[(size_t)r * f.n_steps + f.n_steps - 1];
+  if (rl == 0.0) return;  // last step was not rescaled (norm <= min_norm): tensor unchanged
+  const T s_last = (T)rl;
   T* out = (T*)f.ptrs[(size_t)r * f.n_tensors + f.id_out];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < f.out_numel; i += (int64_t)gridDim.x * 256)
     out[i] = out[i] / s_last;
@@ -457,20 +467,59 @@ __global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
   // epilogue: lazy rescale, store through the C offset tables, abs-sum partial
   const float iA = 1.0f / scA, iB = 1.0f / scB;
   float asum = 0.f;
+  if constexpr (BK >= 32) {
+    // Stage the 128x128 accumulator tile through the (now idle) operand buffers so that every
+    // thread stores whole 16-byte row segments: 16 wide stores per thread instead of 64 dwords.
+    float* sC = smem;  // [BM][BN], 64 KiB <= 2*SZA + 2*SZB
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = wn + j * 32 + l31;
-      const bool cin = n0 + col < a.N;
-      const int offn = s_onC[col];
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (cin && m0 + row < a.M) {
-          const float v = (acc[i][j][e] * iA) * iB;
-          C[s_omC[row] + offn] = v;
-          asum += fabsf(v);
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          sC[row * BN + wn + j * 32 + l31] = (acc[i][j][e] * iA) * iB;
+        }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;
+    const bool cin = n0 + c4 < a.N;  // N % 4 == 0 whenever c_vec, otherwise checked per element
+    const int offn = s_onC[c4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (tid >> 5) + 8 * i;
+      if (m0 + row < a.M && cin) {
+        const float4 v = *reinterpret_cast<const float4*>(sC + row * BN + c4);
+        float* dst = C + s_omC[row];
+        if (a.c_vec) {
+          *reinterpret_cast<float4*>(dst + offn) = v;
+          asum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (n0 + c4 + q < a.N) {
+              dst[s_onC[c4 + q]] = vv[q];
+              asum += fabsf(vv[q]);
+            }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = wn + j * 32 + l31;
+        const bool cin = n0 + col < a.N;
+        const int offn = s_onC[col];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (cin && m0 + row < a.M) {
+            const float v = (acc[i][j][e] * iA) * iB;
+            C[s_omC[row] + offn] = v;
+            asum += fabsf(v);
+          }
         }
       }
     }
@@ -509,6 +558,8 @@ struct Exec {
   double* d_scratch = nullptr;
   double* d_log = nullptr;
   double* d_resc = nullptr;
+  double* d_logs = nullptr;
+  bool outs_aligned16 = true;
   void* d_ones = nullptr;
   int32_t* d_stepP = nullptr;
   double* d_stepNumel = nullptr;
@@ -521,7 +572,7 @@ struct Exec {
   ~Exec() {
     (void)hipSetDevice(device);
     for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch,
-                    (void*)d_log, (void*)d_resc, d_ones, (void*)d_stepP, (void*)d_stepNumel,
+                    (void*)d_log, (void*)d_resc, (void*)d_logs, d_ones, (void*)d_stepP, (void*)d_stepNumel,
                     (void*)d_stage_in, (void*)d_stage_out})
       if (p) (void)hipFree(p);
     for (auto ev : events) (void)hipEventDestroy(ev);
@@ -595,9 +646,11 @@ static int exec_launch_all(Exec* E) {
     a.tiles_n = (int32_t)((st.N + kTileN - 1) / kTileN);
     a.blocks_per_replica = st.blocks;
     a.R = R;
+    a.c_vec = (st.cvec && (s + 1 < P.n_steps || E->outs_aligned16)) ? 1 : 0;
 
-    const size_t ev0 = E->timing_slots ? ((size_t)(E->timing_runs % E->timing_slots) * P.n_steps + s) * 2 : 0;
-    if (E->timing_slots) HIPCHECK(hipEventRecord(E->events[ev0], E->stream));
+    const bool timed = E->timing_runs < E->timing_slots;  // only the first `slots` enqueues are bracketed
+    const size_t ev0 = timed ? ((size_t)E->timing_runs * P.n_steps + s) * 2 : 0;
+    if (timed) HIPCHECK(hipEventRecord(E->events[ev0], E->stream));
     switch (st.kernel) {
       case CTN_KERNEL_MFMA_F32: {
         const int64_t total = (int64_t)st.blocks * R;
@@ -616,7 +669,7 @@ static int exec_launch_all(Exec* E) {
     }
     if (st.collapse)
       hipLaunchKernelGGL(k_collapse, dim3(R), dim3(256), 0, E->stream, (const double*)E->d_scratch, st.blocks, part_dst);
-    if (E->timing_slots) HIPCHECK(hipEventRecord(E->events[ev0 + 1], E->stream));
+    if (timed) HIPCHECK(hipEventRecord(E->events[ev0 + 1], E->stream));
   }
   FinalArgs f;
   f.ptrs = E->d_ptrs;
@@ -631,10 +684,16 @@ static int exec_launch_all(Exec* E) {
   f.stabilize = P.stabilize ? 1 : 0;
   int fb = (int)std::min<int64_t>((P.output().numel + 255) / 256, 1024);
   if (fb < 1) fb = 1;
-  if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_finalize<float>, dim3(fb, R), dim3(256), 0, E->stream, f);
-  else hipLaunchKernelGGL(k_finalize<double>, dim3(fb, R), dim3(256), 0, E->stream, f);
+  const dim3 sg((P.n_steps + 3) / 4, R);
+  if (P.dtype == CTN_F32) {
+    hipLaunchKernelGGL(k_scales<float>, sg, dim3(256), 0, E->stream, f, E->d_logs);
+    hipLaunchKernelGGL(k_finalize<float>, dim3(fb, R), dim3(256), 0, E->stream, f, (const double*)E->d_logs);
+  } else {
+    hipLaunchKernelGGL(k_scales<double>, sg, dim3(256), 0, E->stream, f, E->d_logs);
+    hipLaunchKernelGGL(k_finalize<double>, dim3(fb, R), dim3(256), 0, E->stream, f, (const double*)E->d_logs);
+  }
   HIPCHECK(hipGetLastError());
-  if (E->timing_slots) E->timing_runs++;
+  if (E->timing_runs < E->timing_slots) E->timing_runs++;
   return CTN_OK;
 }
 
@@ -653,6 +712,8 @@ static int exec_set_pointers(Exec* E, const void* const* dev_inputs, void* const
     void* o = dev_outs[r];
     if (!o) { g_err = "null output pointer"; return CTN_INVALID_ARG; }
     if ((uintptr_t)o % P.elem_size()) { g_err = "output pointers must be element aligned"; return CTN_INVALID_ARG; }
+    if (r == 0) E->outs_aligned16 = true;
+    if ((uintptr_t)o % 16) E->outs_aligned16 = false;
     const int id_out = P.n_inputs + P.n_steps - 1;
     if (row[id_out] != o) { row[id_out] = o; changed = true; }
   }
@@ -791,6 +852,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   HIPCHECK_X(hipMalloc((void**)&E.d_scratch, (size_t)replicas * std::max<int64_t>(P.max_collapse_blocks, 1) * 8));
   HIPCHECK_X(hipMalloc((void**)&E.d_log, (size_t)replicas * 8));
   HIPCHECK_X(hipMalloc((void**)&E.d_resc, (size_t)replicas * P.n_steps * 8));
+  HIPCHECK_X(hipMalloc((void**)&E.d_logs, (size_t)replicas * P.n_steps * 8));
   HIPCHECK_X(hipMalloc(&E.d_ones, 256));
   {
     double one64 = 1.0; float one32 = 1.0f;

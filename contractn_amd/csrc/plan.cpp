@@ -287,6 +287,12 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     };
     st.modeA = mode_of(true);
     st.modeB = rhs >= 0 ? mode_of(false) : 0;
+    if (!G[kN].empty()) {
+      const LabelInfo* u = G[kN].back();
+      bool ok = u->sC == 1 && u->ext % vec == 0;
+      for (auto& l : info) if (&l != u && l.inC && l.sC % vec != 0) ok = false;
+      st.cvec = ok;
+    }
 
     // -- kernel choice
     const int64_t outs = st.Bt * st.M * st.N;

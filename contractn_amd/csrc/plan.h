@@ -45,6 +45,7 @@ struct Step {
   int64_t Bt = 1, M = 1, N = 1, K = 1;
   bool has_k = false;  // false: pure product (no summed label)
   int modeA = 0, modeB = 0;
+  bool cvec = false;   // 16-byte vector stores of C are valid (unit-stride column label, aligned strides)
   int blocks = 1;      // workgroups per replica
   int partials = 1;    // partial abs-sums per replica after the optional collapse pass
   bool collapse = false;

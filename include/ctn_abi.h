@@ -145,8 +145,8 @@ int ctn_exec_synchronize(ctn_exec* exec);
 /*
  * Per-step device timing with HIP events recorded on the executor's stream.
  * ctn_exec_set_timing(exec, slots): slots > 0 brackets every step's kernels of
- * the next `slots` enqueues with events (further enqueues reuse the slots
- * round-robin); 0 switches timing off.  ctn_exec_step_ms() waits for the
+ * the next `slots` enqueues with events (later enqueues run without events);
+ * 0 switches timing off.  ctn_exec_step_ms() waits for the
  * stream and returns, per step, the mean duration over the recorded enqueues
  * (ms[n_steps]).
  */
