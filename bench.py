@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--bond", type=int, default=256)
     ap.add_argument("--phys", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split the replicas into this many groups, each on its own HIP stream")
     ap.add_argument("--event-passes", type=int, default=3, help="timed passes bracketed by HIP events")
     ap.add_argument("--dump-steps", default=None, help="write per-step kernel info + mean ms to this JSON file")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline time budget")
@@ -82,7 +84,12 @@ def main():
 
     R = args.replicas
     tn, einstr, shapes, path = build_network(args.sites, args.bond, args.phys)
-    bc = BatchedContraction(einstr, shapes, np.float32, optimize=path, replicas=R, device=local_rank)
+    S = max(1, args.streams)
+    assert R % S == 0, "--replicas must be a multiple of --streams"
+    Rg = R // S
+    groups = [BatchedContraction(einstr, shapes, np.float32, optimize=path, replicas=Rg, device=local_rank)
+              for _ in range(S)]
+    bc = groups[0]
     plan, ex = bc.plan, bc.executor
     infos = plan.step_infos()
 
@@ -100,10 +107,17 @@ def main():
         in_ptrs.extend(base + 4 * int(offs[i]) for i in range(len(shapes)))
     out = torch.zeros(R, max(1, int(np.prod(plan.out_shape))), device=dev, dtype=torch.float32)
     out_ptrs = [out[r].data_ptr() for r in range(R)]
-    launch = ex.make_enqueue(in_ptrs, out_ptrs)
+    n_in = len(shapes)
+    launchers = [g.executor.make_enqueue(in_ptrs[i * Rg * n_in:(i + 1) * Rg * n_in], out_ptrs[i * Rg:(i + 1) * Rg])
+                 for i, g in enumerate(groups)]
+
+    def launch():
+        for fn in launchers:
+            fn()
 
     def sync_all():
-        ex.synchronize()
+        for g in groups:
+            g.executor.synchronize()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -124,7 +138,7 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms_last = ex.step_ms().astype(np.float64)  # per-step mean over the event-bracketed passes
     ex.set_timing(0)
-    logs = bc.fetch_log_scale()
+    logs = np.concatenate([g.fetch_log_scale() for g in groups])
     t_hat = out[:, 0].cpu().numpy()
 
     if world > 1:
@@ -147,7 +161,7 @@ def main():
         key = (info["kernel"], info["mode_a"], info["mode_b"])
         d = by_kernel.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
         d["ms"] += step_ms_last[s]
-        d["flops"] += info["flops"] * R
+        d["flops"] += info["flops"] * Rg
         d["launches"] += 1
     dom_key = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
     dom = by_kernel[dom_key]

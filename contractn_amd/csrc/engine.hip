@@ -529,6 +529,133 @@ __global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// K-mfma-f64: 64x64 workgroup tile, 4 waves (2x2), each wave 32x32 = 2x2
+// v_mfma_f64_16x16x4_f64 accumulators, BK = 16, table-driven gather loads coalesced along the
+// free index, LDS image [k][80] (row stride = 640 B = 32 banks mod 64: the two k rows a 32-lane
+// group reads fall on disjoint bank halves).  f64 C/D map (NOT the f32 one): col = lane & 15,
+// row = (lane >> 4) + 4 * reg.
+// ---------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_mfma_f64(StepArgs a) {
+  constexpr int T64 = kTile64, BK = 16, LD = 80, SZ = BK * LD;
+  __shared__ __attribute__((aligned(16))) double smem[4 * SZ + 8];
+  __shared__ int s_omC[T64], s_onC[T64];
+  double* sA = smem;
+  double* sB = smem + 2 * SZ;
+  double* red = smem + 4 * SZ;
+
+  const int tid = threadIdx.x;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+  const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int r = pid / a.blocks_per_replica;
+  const int t = pid - r * a.blocks_per_replica;
+  const int tiles_mn = a.tiles_m * a.tiles_n;
+  const int b = t / tiles_mn;
+  const int tt = t - b * tiles_mn;
+  const int m0 = (tt / a.tiles_n) * T64;
+  const int n0 = (tt % a.tiles_n) * T64;
+
+  const double scA = producer_scale<double>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const double scB = producer_scale<double>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const double* __restrict__ A = (const double*)tp[a.idA] + a.obA[b];
+  const double* __restrict__ B = (const double*)tp[a.idB] + a.obB[b];
+  double* __restrict__ C = (double*)tp[a.idC] + a.obC[b];
+
+  if (tid < T64) s_omC[tid] = a.omC[m0 + tid];
+  else if (tid < 2 * T64) s_onC[tid - T64] = a.onC[n0 + tid - T64];
+
+  // staging: element (free = tid & 63, k = (tid >> 6) + 4 i), i < 4, for both operands
+  const int fr = tid & 63, kr = tid >> 6;
+  const int offa = a.omA[m0 + fr], offb = a.onB[n0 + fr];
+  const bool ina = m0 + fr < a.M, inb = n0 + fr < a.N;
+  double va[4], vb[4];
+  int ka[4], kb[4];
+  auto tab = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ka[i] = a.okA[k0 + kr + 4 * i]; kb[i] = a.okB[k0 + kr + 4 * i]; }
+  };
+  auto load = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { va[i] = A[offa + ka[i]]; vb[i] = B[offb + kb[i]]; }
+  };
+  auto store = [&](double* dA, double* dB, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool kin = k0 + kr + 4 * i < a.K;
+      dA[(kr + 4 * i) * LD + fr] = (ina && kin) ? va[i] : 0.0;
+      dB[(kr + 4 * i) * LD + fr] = (inb && kin) ? vb[i] : 0.0;
+    }
+  };
+
+  const int lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+  const int l15 = lane & 15, q = lane >> 4;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+
+  const int nkt = (a.K + BK - 1) / BK;
+  tab(0);
+  load();
+  tab(BK);
+  store(sA, sB, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      load();
+      tab((kt + 2) * BK);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const double* cA = sA + cur * SZ;
+    const double* cB = sB + cur * SZ;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int k = kk * 4 + q;
+      const double a0 = cA[k * LD + wm + l15], a1 = cA[k * LD + wm + 16 + l15];
+      const double b0 = cB[k * LD + wn + l15], b1 = cB[k * LD + wn + 16 + l15];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) store(sA + (cur ^ 1) * SZ, sB + (cur ^ 1) * SZ, (kt + 1) * BK);
+    __syncthreads();
+  }
+
+  // epilogue: operands' rescale factors divide the accumulator (division, as in the reference)
+  double asum = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wn + j * 16 + l15;
+      const bool cin = n0 + col < a.N;
+      const int offn = s_onC[col];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = wm + i * 16 + q + 4 * e;
+        if (cin && m0 + row < a.M) {
+          const double v = (acc[i][j][e] / scA) / scB;
+          C[s_omC[row] + offn] = v;
+          asum += fabs(v);
+        }
+      }
+    }
+  const double tot = block_sum(asum, red);
+  if (tid == 0) a.partC[(size_t)r * a.partC_stride + t] = tot;
+}
+
+// ---------------------------------------------------------------------------
 // executor
 // ---------------------------------------------------------------------------
 thread_local std::string g_err;
@@ -656,6 +783,14 @@ static int exec_launch_all(Exec* E) {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
         launch_mfma(st.modeA, st.modeB, dim3((unsigned)total), E->stream, a);
+        break;
+      }
+      case CTN_KERNEL_MFMA_F64: {
+        const int64_t total = (int64_t)st.blocks * R;
+        if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
+        a.tiles_m = (int32_t)((st.M + kTile64 - 1) / kTile64);
+        a.tiles_n = (int32_t)((st.N + kTile64 - 1) / kTile64);
+        hipLaunchKernelGGL(k_mfma_f64, dim3((unsigned)total), dim3(256), 0, E->stream, a);
         break;
       }
       case CTN_KERNEL_DOT:

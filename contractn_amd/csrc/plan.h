@@ -19,7 +19,7 @@ constexpr int kMaxPartials = 64;   // abs-sum partial slots per (step, replica):
 constexpr int kTileM = 128;        // MFMA f32 workgroup tile
 constexpr int kTileN = 128;
 constexpr int kTile64 = 64;        // MFMA f64 workgroup tile
-constexpr bool kEnableMfmaF64 = false;  // flipped once the f64 MFMA kernel lands
+constexpr bool kEnableMfmaF64 = true;
 constexpr int kPadK = 32;          // k-offset tables are padded to this multiple
 constexpr int64_t kAlign = 256;    // byte alignment of workspace tensors
 

@@ -108,3 +108,31 @@ def test_replicas_batched_execution():
         np.testing.assert_array_equal(resc[r], r1[0])
         assert logs[r] == l1[0]
     assert any(i["kernel"] == 2 for i in plan.step_infos()), "expected MFMA steps in this plan"
+
+
+def test_f64_plan_uses_f64_mfma_kernel():
+    g = load_golden("mps_overlap_4x48x4_f64")
+    shapes = tuple(o.shape for o in g["operands"])
+    clist = E._contract_path(g["einsum_str"], shapes, optimize=g["path"], memory_limit=None, use_blas=True)
+    plan = E._native_plan(clist, shapes, "float64")
+    assert any(i["kernel"] == 3 for i in plan.step_infos())
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-12)])
+@pytest.mark.parametrize("einstr,shapes", [
+    ("ab,bc->ac", [(70, 33), (33, 129)]),            # ragged: no dimension a multiple of the tile
+    ("ba,bc->ac", [(40, 200), (40, 36)]),            # A column-major
+    ("ab,cb->ac", [(130, 64), (96, 64)]),            # both k-contiguous
+    ("abc,cbd->ad", [(48, 6, 10), (10, 6, 52)]),     # two contracted labels, different orders
+    ("xab,xbc->xac", [(3, 40, 32), (3, 32, 48)]),    # batch (hyperedge) label on an MFMA step
+    ("ab,bc->ca", [(64, 64), (64, 128)]),            # transposed output (operand swap)
+])
+def test_single_step_shapes_vs_numpy(dtype, tol, einstr, shapes):
+    rng = np.random.default_rng(1)
+    ops = [rng.standard_normal(s).astype(dtype) for s in shapes]
+    t_hat, c = contract(einstr, *ops, split_format=True)
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    got = t_hat.astype(np.float64) * np.exp(float(c))
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)) * 10
+    assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-5  # stabilised: mean |T| == 1
