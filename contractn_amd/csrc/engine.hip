@@ -656,6 +656,60 @@ __global__ __launch_bounds__(256) void k_mfma_f64(StepArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// K-chain: persistent small-tensor DAG walker.  One workgroup per replica executes EVERY step of
+// the plan in order (reference loop einsum.py:341-391) - no per-step launch, rescale factors of
+// all produced tensors kept in LDS.  Same arithmetic as k_element (operands divided by their
+// producer's rescale on load), so results are bit-identical to the per-step path.
+// ---------------------------------------------------------------------------
+struct ChainStep {
+  const int32_t *obA, *obB, *obC, *omA, *omC, *onB, *onC, *okA, *okB;
+  double numelC;
+  int32_t Bt, M, N, K;
+  int32_t idA, idB, idC;
+  int32_t prodA, prodB;  // producing step of each operand, -1 for inputs
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_chain(const ChainStep* __restrict__ steps, int n_steps,
+                                               void* const* ptrs, int n_tensors, double* partials,
+                                               int R, double min_norm, int stabilize) {
+  __shared__ double red[4];
+  __shared__ T sc[kChainMaxSteps];
+  const int r = blockIdx.x;
+  void* const* tp = ptrs + (size_t)r * n_tensors;
+  for (int s = 0; s < n_steps; ++s) {
+    const ChainStep d = steps[s];
+    const T sA = d.prodA >= 0 ? sc[d.prodA] : (T)1;
+    const T sB = d.prodB >= 0 ? sc[d.prodB] : (T)1;
+    const T* __restrict__ A = (const T*)tp[d.idA];
+    const T* __restrict__ B = (const T*)tp[d.idB];
+    T* __restrict__ C = (T*)tp[d.idC];
+    const int total = d.Bt * d.M * d.N;
+    double absv = 0;
+    for (int o = threadIdx.x; o < total; o += 256) {
+      const int n = o % d.N;
+      const int q = o / d.N;
+      const int m = q % d.M;
+      const int b = q / d.M;
+      const T* pa = A + d.obA[b] + d.omA[m];
+      const T* pb = B + d.obB[b] + d.onB[n];
+      T acc = 0;
+      for (int k = 0; k < d.K; ++k) acc = fma(pa[d.okA[k]] / sA, pb[d.okB[k]] / sB, acc);
+      C[d.obC[b] + d.omC[m] + d.onC[n]] = acc;
+      absv += (double)fabs(acc);
+    }
+    // the barriers inside block_sum also order this step's stores before the next step's loads
+    const double tot = block_sum(absv, red);
+    if (threadIdx.x == 0) {
+      partials[((size_t)s * R + r) * kMaxPartials] = tot;
+      const T norm = (T)tot;
+      sc[s] = (stabilize && norm > (T)min_norm) ? norm / (T)d.numelC : (T)1;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // executor
 // ---------------------------------------------------------------------------
 thread_local std::string g_err;
@@ -686,6 +740,9 @@ struct Exec {
   double* d_log = nullptr;
   double* d_resc = nullptr;
   double* d_logs = nullptr;
+  ChainStep* d_chain = nullptr;
+  char* h_pack = nullptr;       // pinned host bounce buffer for many-small-operand staging
+  size_t h_pack_bytes = 0;
   bool outs_aligned16 = true;
   void* d_ones = nullptr;
   int32_t* d_stepP = nullptr;
@@ -699,9 +756,10 @@ struct Exec {
   ~Exec() {
     (void)hipSetDevice(device);
     for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch,
-                    (void*)d_log, (void*)d_resc, (void*)d_logs, d_ones, (void*)d_stepP, (void*)d_stepNumel,
+                    (void*)d_log, (void*)d_resc, (void*)d_logs, (void*)d_chain, d_ones, (void*)d_stepP, (void*)d_stepNumel,
                     (void*)d_stage_in, (void*)d_stage_out})
       if (p) (void)hipFree(p);
+    if (h_pack) (void)hipHostFree(h_pack);
     for (auto ev : events) (void)hipEventDestroy(ev);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -742,7 +800,22 @@ static void launch_mfma(int ma, int mb, dim3 grid, hipStream_t st, const StepArg
 static int exec_launch_all(Exec* E) {
   const Plan& P = *E->plan;
   const int R = E->R;
-  for (int s = 0; s < P.n_steps; ++s) {
+  const bool chain = P.chain && E->d_chain != nullptr;
+  if (chain) {
+    const bool timed = E->timing_runs < E->timing_slots;
+    const size_t ev0 = timed ? (size_t)E->timing_runs * P.n_steps * 2 : 0;
+    if (timed) {
+      HIPCHECK(hipEventRecord(E->events[ev0], E->stream));
+    }
+    if (P.dtype == CTN_F32)
+      hipLaunchKernelGGL(k_chain<float>, dim3(R), dim3(256), 0, E->stream, (const ChainStep*)E->d_chain, P.n_steps,
+                         (void* const*)E->d_ptrs, E->n_tensors, E->d_partials, R, P.min_norm, P.stabilize ? 1 : 0);
+    else
+      hipLaunchKernelGGL(k_chain<double>, dim3(R), dim3(256), 0, E->stream, (const ChainStep*)E->d_chain, P.n_steps,
+                         (void* const*)E->d_ptrs, E->n_tensors, E->d_partials, R, P.min_norm, P.stabilize ? 1 : 0);
+    if (timed) HIPCHECK(hipEventRecord(E->events[ev0 + 1], E->stream));  // whole walk = "step 0"
+  }
+  for (int s = 0; s < P.n_steps && !chain; ++s) {
     const Step& st = P.steps[s];
     StepArgs a;
     const int32_t* T = E->d_tables;
@@ -1001,6 +1074,24 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   HIPCHECK_X(hipMalloc((void**)&E.d_stepNumel, P.n_steps * 8));
   HIPCHECK_X(hipMemcpy(E.d_stepP, sp.data(), P.n_steps * 4, hipMemcpyHostToDevice));
   HIPCHECK_X(hipMemcpy(E.d_stepNumel, sn.data(), P.n_steps * 8, hipMemcpyHostToDevice));
+  if (P.chain) {
+    std::vector<ChainStep> cs(P.n_steps);
+    for (int s = 0; s < P.n_steps; ++s) {
+      const Step& st = P.steps[s];
+      ChainStep& c = cs[s];
+      const int32_t* T = E.d_tables;
+      c.obA = T + st.t.obA; c.obB = T + st.t.obB; c.obC = T + st.t.obC;
+      c.omA = T + st.t.omA; c.omC = T + st.t.omC; c.onB = T + st.t.onB; c.onC = T + st.t.onC;
+      c.okA = T + st.t.okA; c.okB = T + st.t.okB;
+      c.numelC = (double)P.tensors[st.out].numel;
+      c.Bt = (int32_t)st.Bt; c.M = (int32_t)st.M; c.N = (int32_t)st.N; c.K = (int32_t)st.K;
+      c.idA = st.lhs; c.idB = st.rhs >= 0 ? st.rhs : E.n_tensors - 1; c.idC = st.out;
+      c.prodA = st.lhs >= P.n_inputs ? P.tensors[st.lhs].producer : -1;
+      c.prodB = st.rhs >= P.n_inputs ? P.tensors[st.rhs].producer : -1;
+    }
+    HIPCHECK_X(hipMalloc((void**)&E.d_chain, cs.size() * sizeof(ChainStep)));
+    HIPCHECK_X(hipMemcpy(E.d_chain, cs.data(), cs.size() * sizeof(ChainStep), hipMemcpyHostToDevice));
+  }
   // pointer table: intermediates and the ones-scalar are fixed for the executor's lifetime
   E.h_ptrs.assign((size_t)replicas * E.n_tensors, nullptr);
   for (int r = 0; r < replicas; ++r) {
@@ -1060,14 +1151,28 @@ int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space, vo
       hipError_t e_ = hipMalloc((void**)&E->d_stage_in, (size_t)std::max<int64_t>(P.input_bytes_per_replica, 256) * E->R);
       if (e_ != hipSuccess) { g_err = "hipMalloc(input staging) failed"; return e_ == hipErrorOutOfMemory ? CTN_OOM : CTN_HIP_ERROR; }
     }
+    // many small operands: pack them on the host and issue ONE copy (1001 tiny copies cost ms)
+    const size_t total_in = (size_t)P.input_bytes_per_replica * E->R;
+    const bool packed = total_in <= (8u << 20) && (size_t)P.n_inputs * E->R > 8;
+    if (packed && E->h_pack_bytes < total_in) {
+      if (E->h_pack) (void)hipHostFree(E->h_pack);
+      E->h_pack = nullptr; E->h_pack_bytes = 0;
+      if (hipHostMalloc((void**)&E->h_pack, total_in, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); }
+      else E->h_pack_bytes = total_in;
+    }
+    const bool use_pack = packed && E->h_pack;
+    if (use_pack) HIPCHECK(hipStreamSynchronize(E->stream));  // previous copy out of h_pack has finished
     for (int r = 0; r < E->R; ++r)
       for (int i = 0; i < P.n_inputs; ++i) {
         const void* src = inputs[(size_t)r * P.n_inputs + i];
         if (!src) { g_err = "null operand pointer"; return CTN_INVALID_ARG; }
-        char* dst = E->d_stage_in + (size_t)r * P.input_bytes_per_replica + P.input_offsets[i];
-        HIPCHECK(hipMemcpyAsync(dst, src, (size_t)P.tensors[i].numel * es, hipMemcpyHostToDevice, E->stream));
+        const size_t off = (size_t)r * P.input_bytes_per_replica + P.input_offsets[i];
+        char* dst = E->d_stage_in + off;
+        if (use_pack) memcpy(E->h_pack + off, src, (size_t)P.tensors[i].numel * es);
+        else HIPCHECK(hipMemcpyAsync(dst, src, (size_t)P.tensors[i].numel * es, hipMemcpyHostToDevice, E->stream));
         din[(size_t)r * P.n_inputs + i] = dst;
       }
+    if (use_pack) HIPCHECK(hipMemcpyAsync(E->d_stage_in, E->h_pack, total_in, hipMemcpyHostToDevice, E->stream));
   } else {
     for (size_t i = 0; i < din.size(); ++i) din[i] = inputs[i];
   }
@@ -1115,8 +1220,10 @@ int ctn_exec_step_ms(ctn_exec* exec, float* ms) {
   if (used < 1) { g_err = "no timed run recorded: call ctn_exec_set_timing(slots) then enqueue"; return CTN_INVALID_ARG; }
   HIPCHECK(hipStreamSynchronize(E->stream));
   const int ns = E->plan->n_steps;
+  const bool chain = E->plan->chain && E->d_chain != nullptr;
   for (int s = 0; s < ns; ++s) {
     double acc = 0;
+    if (chain && s > 0) { ms[s] = 0.f; continue; }  // the persistent walker is one launch, timed as step 0
     for (int slot = 0; slot < used; ++slot) {
       float t = 0;
       const size_t ev0 = ((size_t)slot * ns + s) * 2;

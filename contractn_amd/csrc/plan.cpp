@@ -344,6 +344,14 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
   for (int id = 0; id < d.n_inputs + d.n_steps - 1; ++id) {
     if (!consumed[id]) { err = fmt("tensor %lld is never contracted: the path must reduce the network to one tensor", id); return CTN_INVALID_ARG; }
   }
+  // latency-bound DAGs (e.g. 1000 dependent 3x3 products): no per-step launch at all
+  P.chain = d.n_steps >= 4 && d.n_steps <= kChainMaxSteps;
+  for (const Step& st : P.steps) {
+    const int64_t outs = st.Bt * st.M * st.N;
+    if (outs > kChainMaxOut || outs * st.K > kChainMaxWork) P.chain = false;
+  }
+  if (P.chain)
+    for (Step& st : P.steps) { st.partials = 1; st.collapse = false; }
   P.ws_bytes_per_replica = arena.top;
   P.bytes_min += P.output().numel * es;
   return CTN_OK;

@@ -21,6 +21,9 @@ constexpr int kTileN = 128;
 constexpr int kTile64 = 64;        // MFMA f64 workgroup tile
 constexpr bool kEnableMfmaF64 = true;
 constexpr int kPadK = 32;          // k-offset tables are padded to this multiple
+constexpr int kChainMaxSteps = 4096;   // rescale factors of all steps live in LDS
+constexpr int64_t kChainMaxOut = 4096;  // per-step output elements
+constexpr int64_t kChainMaxWork = 1 << 16;  // per-step multiply-adds
 constexpr int64_t kAlign = 256;    // byte alignment of workspace tensors
 
 struct Tensor {
@@ -66,6 +69,7 @@ struct Plan {
   int64_t input_bytes_per_replica = 0;  // staging size when operands arrive as host pointers
   std::vector<int64_t> input_offsets;   // byte offset of each input inside the staging block
   int64_t max_collapse_blocks = 0;
+  bool chain = false;  // every step is tiny: one persistent workgroup per replica walks the whole DAG
   double flops = 0;
   int64_t bytes_min = 0;
 

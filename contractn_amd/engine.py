@@ -76,6 +76,34 @@ class StepInfo(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.
+
+    PyTorch-ROCm ships its own ``libamdhip64.so`` (soname ``libamdhip64.so.7``) and asks for it by
+    the unversioned file name, so if our library pulled in ``/opt/rocm/lib/libamdhip64.so.7`` first
+    a later ``import torch`` would load a second copy of the runtime and see no GPU.  When torch is
+    installed, map its copy first (without importing torch): our ``NEEDED libamdhip64.so.7`` then
+    resolves to it by soname, whichever of the two is used first.
+    """
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """Load the engine library (built by ``__graft_entry__.build()`` / csrc/Makefile)."""
     global _lib
@@ -86,6 +114,7 @@ def load_library():
             f"HIP engine library not found at {LIB_PATH}; build it with "
             "`make -C contractn_amd/csrc` (there is no CPU fallback)"
         )
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
     sig = {
@@ -250,9 +279,10 @@ class Executor:
         for r, ops in enumerate(operand_sets):
             assert len(ops) == plan.n_inputs
             for i, op in enumerate(ops):
-                arr = np.ascontiguousarray(op, dtype=plan.np_dtype)
-                keep.append(arr)
-                ptrs[r * plan.n_inputs + i] = arr.ctypes.data
+                if not (isinstance(op, np.ndarray) and op.dtype == plan.np_dtype and op.flags.c_contiguous):
+                    op = np.ascontiguousarray(op, dtype=plan.np_dtype)
+                    keep.append(op)
+                ptrs[r * plan.n_inputs + i] = op.__array_interface__["data"][0]
         outs = np.empty((R,) + plan.out_shape, dtype=plan.np_dtype)
         optrs = (C.c_void_p * R)()
         stride = outs[0].nbytes if R else 0

@@ -157,3 +157,30 @@ def batched_mps(TN, n_sites, bond, phys, batch, dtype=np.float32, seed=4):
         tn.connect_nodes(hub, inp, i, 0)
         inputs.append(_rand(rng, (batch, phys), 1.0, dtype))
     return tn, inputs
+
+
+def peps_row_path(rows, cols):
+    """SSA path for peps_closed(): absorb every physical vector into its site, then sweep the
+    sites row by row into one boundary tensor (largest intermediate: bond ** (cols + 1))."""
+    n = rows * cols
+    path = [(i, n + i) for i in range(n)]          # site_i x vec_i -> id 2n + i
+    cur = 2 * n
+    nxt = 3 * n
+    for i in range(1, n):
+        path.append((cur, 2 * n + i))
+        cur = nxt
+        nxt += 1
+    return path
+
+
+def batched_mps_path(n_sites):
+    """SSA sweep for batched_mps(): per site one GEMM (batch x bond) . (bond x phys*bond) followed by
+    the hyperedge step 'apr,ap->ar' that feeds the batched input in."""
+    n = n_sites
+    path = [(0, n)]
+    cur, nxt = 2 * n, 2 * n + 1
+    for i in range(1, n):
+        path.append((cur, i))
+        path.append((nxt, n + i))
+        cur, nxt = nxt + 1, nxt + 2
+    return path

@@ -1,0 +1,135 @@
+"""BASELINE configs 3a/3b/4/5 at realistic sizes on the GPU: oracle comparisons where the CPU
+finishes in seconds, size-independent properties (linearity, batch independence, CP == Tucker
+with a materialised copy tensor, sliced == unsliced) beyond that."""
+import numpy as np
+import pytest
+
+from contractn_amd import TN, contract, dist
+from contractn_amd import einsum as E
+from contractn_amd.paths import ssa_to_linear
+from oracle import cpu_ref
+from tests import networks as nets
+
+pytestmark = pytest.mark.gpu
+
+
+def full(t, c):
+    return np.asarray(t, dtype=np.float64) * np.exp(float(c))
+
+
+def test_cfg3a_mps_overlap_bond256_vs_oracle():
+    """Headline shapes (D=256, d=4, fp32, zipper path) at 12 sites; tolerance 1e-3 (north_star)."""
+    tn, ssa = nets.mps_overlap(TN, 12, 256, 4, dtype=np.float32, seed=3)
+    path = ssa_to_linear(ssa, 24)
+    t, c = tn.contract(optimize=path, split_format=True)
+    rt, rc = cpu_ref.contract(tn.einsum_str, *tn.params, path=path, split_format=True)
+    assert t.dtype == np.float32 and abs(float(t)) == 1.0 and float(t) == float(rt)
+    # scalar overlap of random states = a sum with cancellation: both fp32 paths carry ~1e-5 rel. error
+    assert abs(float(c) - float(rc)) <= 1e-4 * max(1.0, abs(float(rc)))
+    infos = E._native_plan(E._contract_path(tn.einsum_str, tuple(p.shape for p in tn.params), optimize=path,
+                                            memory_limit=None, use_blas=True),
+                           tuple(p.shape for p in tn.params), "float32").step_infos()
+    assert sum(i["kernel"] == 2 for i in infos) == 20  # all bulk steps are MFMA GEMMs
+
+
+def test_cfg3a_linearity_of_the_log_register():
+    """Scaling one core by 2^k shifts the register by exactly k ln 2 and leaves T_hat unchanged."""
+    tn, ssa = nets.mps_overlap(TN, 8, 128, 4, dtype=np.float32, seed=5)
+    path = ssa_to_linear(ssa, 16)
+    params = list(tn.params)
+    fun = tn.make_contract_fun(optimize=path, split_format=True)
+    t0, c0 = fun(tuple(params), ())
+    params[3] = params[3] * np.float32(8.0)
+    t1, c1 = fun(tuple(params), ())
+    assert float(t1) == float(t0)
+    assert abs((float(c1) - float(c0)) - 3 * np.log(2.0)) < 1e-6
+
+
+def test_cfg3b_batched_inputs_through_batch_hyperedge():
+    B, n_sites, bond, phys = 1024, 10, 64, 4
+    tn, inputs = nets.batched_mps(TN, n_sites, bond, phys, B, dtype=np.float32, seed=4)
+    path = ssa_to_linear(nets.batched_mps_path(n_sites), 2 * n_sites)
+    fun = tn.make_contract_fun(optimize=path, split_format=True)
+    t, c = fun(tn.params, inputs)
+    assert t.shape == (B,)
+    got = full(t, c)
+    # oracle on the whole batch (CPU: fine at this size)
+    ops = E.make_arg_packer(tn)(tn.params, inputs)
+    shapes = tuple(o.shape for o in ops)
+    clist = E._contract_path(tn.einsum_str, shapes, optimize=path, memory_limit=None, use_blas=True)
+    rt, rc, _ = cpu_ref.core_contract(list(ops), clist)
+    ref = full(rt, rc)
+    assert np.max(np.abs(got - ref)) <= 1e-3 * np.max(np.abs(ref))
+    # batch independence: element j equals the contraction of input row j alone
+    for j in (0, 517, B - 1):
+        single = [np.ascontiguousarray(x[j:j + 1]) for x in inputs]
+        tj, cj = fun(tn.params, single)
+        assert abs(full(tj, cj)[0] - got[j]) <= 1e-3 * np.max(np.abs(ref))
+    # the hyperedge is a batch index: no step materialises anything larger than B x bond
+    plan = E._native_plan(clist, shapes, "float32")
+    assert max(i["out_numel"] for i in plan.step_infos()) <= B * bond * phys
+    infos = plan.step_infos()
+    assert any(i["kernel"] == 2 and B in (i["m"], i["n"]) for i in infos)      # GEMM with M = batch
+    assert sum(i["batch"] == B for i in infos) >= n_sites - 1                   # hyperedge steps
+
+
+def test_cfg4_cp_hyperedge_equals_tucker_with_delta_hub():
+    r, n = 192, 160
+    cp = nets.cp_network(TN, r, (n, n, n), dtype=np.float32, seed=5, scale=4.0)
+    tk = nets.tucker_network(TN, (r, r, r), (n, n, n), dtype=np.float32, seed=5, scale=4.0, delta_hub=True)
+    assert cp.einsum_str == "ac,ad,ae->cde"
+    a = full(*cp.contract(split_format=True))
+    b = full(*tk.contract(split_format=True))
+    assert a.shape == (n, n, n)
+    assert np.max(np.abs(a - b)) <= 1e-3 * np.max(np.abs(a))
+    # spot-check entries against the definition sum_a A[a,c] B[a,d] C[a,e]
+    A, Bm, C = [p.astype(np.float64) for p in cp.params]
+    rng = np.random.default_rng(0)
+    for c_, d_, e_ in rng.integers(0, n, size=(20, 3)):
+        ref = np.sum(A[:, c_] * Bm[:, d_] * C[:, e_])
+        assert abs(a[c_, d_, e_] - ref) <= 1e-3 * np.max(np.abs(a))
+
+
+def test_cfg4_tucker_dense_hub_vs_numpy():
+    tk = nets.tucker_network(TN, (96, 80, 64), (128, 96, 112), dtype=np.float32, seed=6, scale=8.0)
+    got = full(*tk.contract(split_format=True))
+    hub, m0, m1, m2 = [p.astype(np.float64) for p in tk.params]
+    ref = np.einsum("abc,ae,bf,cg->efg", hub, m0, m1, m2, optimize=True)
+    assert np.max(np.abs(got - ref)) <= 1e-3 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("rows,cols,bond,dtype,tol", [(4, 4, 3, np.float64, 1e-9), (5, 5, 4, np.float32, 1e-3)])
+def test_cfg5_peps_row_sweep_vs_oracle(rows, cols, bond, dtype, tol):
+    tn = nets.peps_closed(TN, rows, cols, bond, dtype=dtype, seed=6)
+    path = ssa_to_linear(nets.peps_row_path(rows, cols), 2 * rows * cols)
+    t, c = tn.contract(optimize=path, split_format=True)
+    rt, rc = cpu_ref.contract(tn.einsum_str, *tn.params, path=path, split_format=True)
+    assert abs(float(t)) == 1.0 and float(t) == float(rt)
+    assert abs(float(c) - float(rc)) <= tol * max(1.0, abs(float(rc)))
+
+
+def test_cfg5_peps_sliced_equals_unsliced():
+    """Index slicing (the multi-GPU decomposition) over three bulk bonds, world = 1."""
+    rows = cols = 6
+    tn = nets.peps_closed(TN, rows, cols, 4, dtype=np.float32, seed=6)
+    path = ssa_to_linear(nets.peps_row_path(rows, cols), 2 * rows * cols)
+    t, c = tn.contract(optimize=path, split_format=True)
+    lhs, _ = tn.einsum_str.split("->")
+    terms = lhs.split(",")
+    # three vertical bonds in the middle of the grid (shared by site (2,c) and site (3,c))
+    labels = tuple(next(iter(set(terms[2 * cols + k]) & set(terms[3 * cols + k]))) for k in (1, 2, 3))
+    ts, cs = dist.contract_sliced(tn.einsum_str, list(tn.params), labels, optimize="greedy", rank=0, world=1)
+    assert abs(full(ts, cs) - full(t, c)) <= 2e-3 * abs(full(t, c))
+
+
+def test_torch_device_tensors_zero_copy():
+    import torch
+
+    g_ops = [torch.randn(64, 96, device="cuda"), torch.randn(96, 80, device="cuda")]
+    t, c = contract("ab,bc->ac", *g_ops, split_format=True)
+    assert t.is_cuda and t.dtype == torch.float32 and c.is_cuda
+    ref = (g_ops[0].double() @ g_ops[1].double())
+    got = t.double() * torch.exp(c.double())
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
+    out = contract("ab,bc->ac", *g_ops)
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 1e-5
