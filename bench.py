@@ -70,11 +70,18 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
+    # rehearsal knobs (one-GPU box): CTN_BENCH_BACKEND=gloo + CTN_BENCH_ONE_DEVICE=1 run all ranks on cuda:0
+    backend = os.environ.get("CTN_BENCH_BACKEND", "nccl")
+    if os.environ.get("CTN_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -142,7 +149,7 @@ def main():
     t_hat = out[:, 0].cpu().numpy()
 
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
