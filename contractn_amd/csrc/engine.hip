@@ -467,61 +467,52 @@ __global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
   // epilogue: lazy rescale, store through the C offset tables, abs-sum partial
   const float iA = 1.0f / scA, iB = 1.0f / scB;
   float asum = 0.f;
-  if constexpr (BK >= 32) {
-    // Stage the 128x128 accumulator tile through the (now idle) operand buffers so that every
-    // thread stores whole 16-byte row segments: 16 wide stores per thread instead of 64 dwords.
-    float* sC = smem;  // [BM][BN], 64 KiB <= 2*SZA + 2*SZB
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          sC[row * BN + wn + j * 32 + l31] = (acc[i][j][e] * iA) * iB;
-        }
-    __syncthreads();
+  {
+    // Stage the accumulator tile through the (now idle) operand buffers so that every thread
+    // stores whole 16-byte row segments: wide stores instead of 64 dwords per thread.  BK = 32
+    // has room for all 128 rows at once, BK = 16 (32 KiB of LDS) does two 64-row halves.
+    constexpr int NH = BK >= 32 ? 1 : 2;
+    constexpr int ROWS = BM / NH;
+    float* sC = smem;  // [ROWS][BN]
     const int c4 = (tid & 31) * 4;
     const bool cin = n0 + c4 < a.N;  // N % 4 == 0 whenever c_vec, otherwise checked per element
     const int offn = s_onC[c4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (tid >> 5) + 8 * i;
-      if (m0 + row < a.M && cin) {
-        const float4 v = *reinterpret_cast<const float4*>(sC + row * BN + c4);
-        float* dst = C + s_omC[row];
-        if (a.c_vec) {
-          *reinterpret_cast<float4*>(dst + offn) = v;
-          asum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
-        } else {
-          const float vv[4] = {v.x, v.y, v.z, v.w};
+    for (int hh = 0; hh < NH; ++hh) {
+      if (NH == 1 || (w >> 1) == hh) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (n0 + c4 + q < a.N) {
-              dst[s_onC[c4 + q]] = vv[q];
-              asum += fabsf(vv[q]);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = (NH == 1 ? wm : 0) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              sC[row * BN + wn + j * 32 + l31] = (acc[i][j][e] * iA) * iB;
             }
-        }
       }
-    }
-  } else {
+      __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < ROWS / 8; ++i) {
+        const int lrow = (tid >> 5) + 8 * i;
+        const int row = hh * ROWS + lrow;
+        if (m0 + row < a.M && cin) {
+          const float4 v = *reinterpret_cast<const float4*>(sC + lrow * BN + c4);
+          float* dst = C + s_omC[row];
+          if (a.c_vec) {
+            *reinterpret_cast<float4*>(dst + offn) = v;
+            asum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+          } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = wn + j * 32 + l31;
-        const bool cin = n0 + col < a.N;
-        const int offn = s_onC[col];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (cin && m0 + row < a.M) {
-            const float v = (acc[i][j][e] * iA) * iB;
-            C[s_omC[row] + offn] = v;
-            asum += fabsf(v);
+            for (int q = 0; q < 4; ++q)
+              if (n0 + c4 + q < a.N) {
+                dst[s_onC[c4 + q]] = vv[q];
+                asum += fabsf(vv[q]);
+              }
           }
         }
       }
+      if (hh + 1 < NH) __syncthreads();
     }
   }
   const double tot = block_sum((double)asum, red);
@@ -783,17 +774,22 @@ static void launch_mfma_a(int ma, int mb, dim3 grid, hipStream_t st, const StepA
   }
 }
 
-// tuning knob (development only): CTN_MFMA_BK=16|32 selects the k-tile depth
-static int mfma_bk() {
-  static int bk = [] {
+// k-tile depth.  BK = 16: 32 KiB of LDS + 167 registers => 3 workgroups (12 waves) per CU, which
+// hides the per-tile prologue/epilogue best when K is short (MPS shapes: 108-118 TFLOP/s vs
+// 103-117 with BK = 32); BK = 32 halves the barriers per flop and wins on long-K GEMMs
+// (4096^3: 130 vs 115 TFLOP/s).  CTN_MFMA_BK=16|32 forces one of them (development knob).
+static int mfma_bk(int K) {
+  static int forced = [] {
     const char* e = getenv("CTN_MFMA_BK");
-    return (e && atoi(e) == 16) ? 16 : 32;
+    const int v = e ? atoi(e) : 0;
+    return (v == 16 || v == 32) ? v : 0;
   }();
-  return bk;
+  if (forced) return forced;
+  return K >= 2048 ? 32 : 16;
 }
 
 static void launch_mfma(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
-  if (mfma_bk() == 16) launch_mfma_a<16>(ma, mb, grid, st, a);
+  if (mfma_bk(a.K) == 16) launch_mfma_a<16>(ma, mb, grid, st, a);
   else launch_mfma_a<32>(ma, mb, grid, st, a);
 }
 
