@@ -31,6 +31,26 @@ namespace ctn {
 // ---------------------------------------------------------------------------
 // kernel arguments
 // ---------------------------------------------------------------------------
+// n / d for 0 <= n < 2^31 by multiply-shift (host-precomputed): exact, ~5 instructions instead of
+// the ~40 (32-bit) / ~100 (64-bit) of a hardware-less integer division.
+struct FastDiv {
+  uint64_t M;
+  uint32_t d;
+  int32_t k;
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return (uint32_t)(((uint64_t)n * M) >> k); }
+};
+static FastDiv make_fastdiv(int64_t d64) {
+  FastDiv f;
+  const uint32_t d = (uint32_t)std::max<int64_t>(d64, 1);
+  int lg = 0;
+  while ((1ull << lg) < d) ++lg;
+  f.d = d;
+  f.k = 31 + lg;
+  f.M = ((1ull << f.k) / d) + 1;   // n * M < 2^31 * 2^(32) fits in 64 bits; exact for n < 2^31
+  if (d == 1) { f.M = 1; f.k = 0; }
+  return f;
+}
+
 struct StepArgs {
   const int32_t *obA, *obB, *obC, *omA, *omC, *onB, *onC, *okA, *okB;
   void* const* ptrs;    // [R][n_tensors] base pointer of every tensor of every replica
@@ -47,6 +67,10 @@ struct StepArgs {
   int32_t blocks_per_replica;
   int32_t R;
   int32_t c_vec;  // float4 stores of C allowed
+  // streaming kernels: output index = (hi, lo, n); n along C's unit-stride label
+  const int32_t *ohA, *ohB, *ohC, *olA, *olB, *olC;
+  int32_t H, L, Nv, sAn, sBn;
+  FastDiv dNq, dL, dNv;  // divisors: vectors per row, lo extent, n extent
 };
 
 struct FinalArgs {
@@ -99,39 +123,160 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 }
 
 // ---------------------------------------------------------------------------
-// K-element: one thread per output element.  Hyperedge (batch) products,
-// Khatri-Rao, traces, tiny GEMVs - everything that is not worth a tile.
+// K-element ("stream"): copy-tensor / hyperedge products, Khatri-Rao, Hadamard, traces, small-K
+// steps.  HBM-bound gather-multiply: the output index space is (hi, lo, n) with n running along C's
+// unit-stride label; one thread produces V consecutive n (one 16-byte store), consecutive lanes
+// consecutive vectors, so C is written - and every operand that is unit-stride along n is read -
+// in full cache lines; an operand that does not carry the label is a per-thread broadcast.  No
+// identity tensor exists anywhere: a copy tensor is only the shared (hi/lo/n) index.
+// Operands are divided by their producer's rescale on load, exactly like the reference's
+// stabilize() output feeding the next step: bit-identical when the K sum is exact.
 // ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_element(StepArgs a) {
+template <typename T, int V>
+struct VecOf;
+template <> struct VecOf<float, 4> { typedef float4 type; };
+template <> struct VecOf<double, 2> { typedef double2 type; };
+template <typename T> struct VecOf<T, 1> { typedef T type; };
+
+template <typename T, int V>
+__device__ __forceinline__ void load_vec(const T* __restrict__ p, int stride_n, T (&out)[V]) {
+  if constexpr (V == 1) {
+    out[0] = p[0];
+  } else {
+    if (stride_n == 0) {
+      const T x = p[0];
+#pragma unroll
+      for (int v = 0; v < V; ++v) out[v] = x;
+    } else {
+      typedef typename VecOf<T, V>::type VT;
+      const VT x = *reinterpret_cast<const VT*>(p);
+      const T* e = reinterpret_cast<const T*>(&x);
+#pragma unroll
+      for (int v = 0; v < V; ++v) out[v] = e[v];
+    }
+  }
+}
+
+template <typename T, int V, int U>
+__global__ __launch_bounds__(256) void k_stream(StepArgs a) {
   __shared__ double red[4];
   const int r = blockIdx.y;
   const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
   const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const bool divA = sA != (T)1, divB = sB != (T)1;
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const T* __restrict__ A = (const T*)tp[a.idA];
   const T* __restrict__ B = (const T*)tp[a.idB];
   T* __restrict__ C = (T*)tp[a.idC];
-  const int64_t total = (int64_t)a.Bt * a.M * a.N;
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // one item = U vectors of V elements of one output row (hi, lo): columns c, c + S, ..., c + (U-1) S
+  // with S = vectors per row / U, so the row's table lookups and broadcast operands are paid once
+  // per U*V outputs while every store instruction of a wave still covers a contiguous segment.
+  const uint32_t nq_per = (uint32_t)((a.Nv + V - 1) / V);
+  const uint32_t S = nq_per / U;                 // U divides nq_per (checked on the host)
+  const uint32_t items = (uint32_t)a.H * (uint32_t)a.L * S;  // < 2^31
+  const FastDiv dq = a.dNq;                      // divisor S
+  const bool kone = a.K == 1;                    // pure product: k-offset tables hold a single 0
   double absv = 0;
-  if (o < total) {
-    const int n = (int)(o % a.N);
-    const int64_t q = o / a.N;
-    const int m = (int)(q % a.M);
-    const int b = (int)(q / a.M);
-    const T* pa = A + a.obA[b] + a.omA[m];
-    const T* pb = B + a.obB[b] + a.onB[n];
-    // operands are normalised on load, (A/sA)*(B/sB), exactly like the reference's
-    // stabilize() output feeding the next step: bit-identical when the K sum is exact
-    T acc = 0;
-    for (int k = 0; k < a.K; ++k) acc = fma(pa[a.okA[k]] / sA, pb[a.okB[k]] / sB, acc);
-    const T v = acc;
-    C[a.obC[b] + a.omC[m] + a.onC[n]] = v;
-    absv = (double)fabs(v);
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += stride) {
+    const uint32_t row = dq.div(it);
+    const int c0 = (int)(it - row * S) * V;
+    const int h = (int)a.dL.div(row);
+    const int l = (int)(row - (uint32_t)h * (uint32_t)a.L);
+    const T* pa = A + a.ohA[h] + a.olA[l] + c0 * a.sAn;
+    const T* pb = B + a.ohB[h] + a.olB[l] + c0 * a.sBn;
+    T* pc = C + (size_t)row * a.Nv + c0;         // C is contiguous in (hi, lo, n) order
+    T acc[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[u][v] = 0;
+    const int stepA = (int)S * V * a.sAn, stepB = (int)S * V * a.sBn;
+    for (int k = 0; k < a.K; ++k) {
+      const int ka = kone ? 0 : a.okA[k], kb = kone ? 0 : a.okB[k];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        T av[V], bv[V];
+        load_vec<T, V>(pa + ka + u * stepA, a.sAn, av);
+        load_vec<T, V>(pb + kb + u * stepB, a.sBn, bv);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const T x = divA ? av[v] / sA : av[v];
+          const T y = divB ? bv[v] / sB : bv[v];
+          acc[u][v] = fma(x, y, acc[u][v]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (V == 1) {
+        pc[u * S] = acc[u][0];
+      } else {
+        typedef typename VecOf<T, V>::type VT;
+        VT o;
+        T* e = reinterpret_cast<T*>(&o);
+#pragma unroll
+        for (int v = 0; v < V; ++v) e[v] = acc[u][v];
+        *reinterpret_cast<VT*>(pc + u * S * V) = o;
+      }
+      T part = 0;
+#pragma unroll
+      for (int v = 0; v < V; ++v) part += fabs(acc[u][v]);
+      absv += (double)part;
+    }
   }
   const double tot = block_sum(absv, red);
   if (threadIdx.x == 0) a.partC[(size_t)r * a.partC_stride + blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// K-rowdot: one WAVE per output element, the 64 lanes stride a unit-stride K (coalesced
+// 256-byte reads), xor-butterfly reduction.  GEMV / batched-dot shaped steps.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_rowdot(StepArgs a) {
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const bool divA = sA != (T)1, divB = sB != (T)1;
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const T* __restrict__ A = (const T*)tp[a.idA];
+  const T* __restrict__ B = (const T*)tp[a.idB];
+  T* __restrict__ C = (T*)tp[a.idC];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t outs = (uint32_t)a.H * (uint32_t)a.L * (uint32_t)a.Nv;
+  double mine = 0;
+  for (uint32_t o = blockIdx.x * 4u + w; o < outs; o += gridDim.x * 4u) {  // wave-uniform
+    const uint32_t o2 = a.dNv.div(o);
+    const int n = (int)(o - o2 * (uint32_t)a.Nv);
+    const int h = (int)a.dL.div(o2);
+    const int l = (int)(o2 - (uint32_t)h * (uint32_t)a.L);
+    const T* pa = A + a.ohA[h] + a.olA[l] + (int64_t)n * a.sAn;
+    const T* pb = B + a.ohB[h] + a.olB[l] + (int64_t)n * a.sBn;
+    T acc0 = 0, acc1 = 0;
+    int k = lane;
+    for (; k + 64 < a.K; k += 128) {
+      const T x0 = pa[a.okA[k]], y0 = pb[a.okB[k]];
+      const T x1 = pa[a.okA[k + 64]], y1 = pb[a.okB[k + 64]];
+      acc0 = fma(divA ? x0 / sA : x0, divB ? y0 / sB : y0, acc0);
+      acc1 = fma(divA ? x1 / sA : x1, divB ? y1 / sB : y1, acc1);
+    }
+    if (k < a.K) {
+      const T x0 = pa[a.okA[k]], y0 = pb[a.okB[k]];
+      acc0 = fma(divA ? x0 / sA : x0, divB ? y0 / sB : y0, acc0);
+    }
+    double v = (double)acc0 + (double)acc1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const T res = (T)v;
+    if (lane == 0) C[a.ohC[h] + a.olC[l] + n] = res;
+    mine += (double)fabs(res);
+  }
+  if (lane == 0) red[w] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    a.partC[(size_t)r * a.partC_stride + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 // ---------------------------------------------------------------------------
@@ -843,6 +988,13 @@ static int exec_launch_all(Exec* E) {
     a.blocks_per_replica = st.blocks;
     a.R = R;
     a.c_vec = (st.cvec && (s + 1 < P.n_steps || E->outs_aligned16)) ? 1 : 0;
+    a.ohA = T + st.t.ohA; a.ohB = T + st.t.ohB; a.ohC = T + st.t.ohC;
+    a.olA = T + st.t.olA; a.olB = T + st.t.olB; a.olC = T + st.t.olC;
+    a.H = (int32_t)st.H; a.L = (int32_t)st.L; a.Nv = (int32_t)st.Nv;
+    a.sAn = (int32_t)st.sAn; a.sBn = (int32_t)st.sBn;
+    a.dNq = make_fastdiv((st.Nv + st.vecw - 1) / st.vecw);
+    a.dL = make_fastdiv(st.L);
+    a.dNv = make_fastdiv(st.Nv);
 
     const bool timed = E->timing_runs < E->timing_slots;  // only the first `slots` enqueues are bracketed
     const size_t ev0 = timed ? ((size_t)E->timing_runs * P.n_steps + s) * 2 : 0;
@@ -866,10 +1018,28 @@ static int exec_launch_all(Exec* E) {
         if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_dot<float>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
         else hipLaunchKernelGGL(k_dot<double>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
         break;
-      default:
-        if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_element<float>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
-        else hipLaunchKernelGGL(k_element<double>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
+      case CTN_KERNEL_ROWDOT:
+        if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_rowdot<float>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
+        else hipLaunchKernelGGL(k_rowdot<double>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
         break;
+      default: {
+        // vector stores need a 16-byte aligned destination: the caller's final buffer may not be
+        const int vw = (s + 1 == P.n_steps && !E->outs_aligned16) ? 1 : st.vecw;
+        const int64_t nq = (st.Nv + vw - 1) / vw;
+        const int u = (nq % 4 == 0) ? 4 : 1;
+        a.dNq = make_fastdiv(nq / u);
+        const dim3 g(st.blocks, R), b(256);
+#define CTN_STREAM(TT, VV, UU) hipLaunchKernelGGL((k_stream<TT, VV, UU>), g, b, 0, E->stream, a)
+        if (P.dtype == CTN_F32) {
+          if (vw == 4) { if (u == 4) CTN_STREAM(float, 4, 4); else CTN_STREAM(float, 4, 1); }
+          else { if (u == 4) CTN_STREAM(float, 1, 4); else CTN_STREAM(float, 1, 1); }
+        } else {
+          if (vw == 2) { if (u == 4) CTN_STREAM(double, 2, 4); else CTN_STREAM(double, 2, 1); }
+          else { if (u == 4) CTN_STREAM(double, 1, 4); else CTN_STREAM(double, 1, 1); }
+        }
+#undef CTN_STREAM
+        break;
+      }
     }
     if (st.collapse)
       hipLaunchKernelGGL(k_collapse, dim3(R), dim3(256), 0, E->stream, (const double*)E->d_scratch, st.blocks, part_dst);

@@ -306,11 +306,60 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       st.kernel = CTN_KERNEL_DOT;
       st.blocks = (int)outs;
     } else {
-      st.kernel = CTN_KERNEL_ELEMENT;
-      int64_t b = (outs + 255) / 256;
-      if (b >= (1LL << 31)) { err = "step output too large"; return CTN_UNSUPPORTED; }
-      st.blocks = (int)b;
+      // streaming decomposition: n = C's unit-stride label, the other C labels split into (hi, lo)
+      std::vector<const LabelInfo*> cl;
+      for (int32_t lab : out.labels) cl.push_back(find(lab));
+      const LabelInfo* nl = nullptr;
+      if (!cl.empty()) { nl = cl.back(); cl.pop_back(); }
+      st.Nv = nl ? nl->ext : 1;
+      st.sAn = nl && nl->inA ? nl->sA : 0;
+      st.sBn = nl && nl->inB ? nl->sB : 0;
+      std::vector<const LabelInfo*> lo, hi;
+      int64_t lprod = 1;
+      while (!cl.empty() && (lo.empty() || lprod * cl.back()->ext <= 65536)) {
+        lprod *= cl.back()->ext;
+        lo.insert(lo.begin(), cl.back());
+        cl.pop_back();
+      }
+      hi = cl;
+      st.L = lprod;
+      st.H = 1;
+      for (auto* l : hi) st.H *= l->ext;
+      std::vector<int32_t> t6;
+      build_table(hi, 0, st.H, t6); st.t.ohA = append(P.tables, t6);
+      build_table(hi, 1, st.H, t6); st.t.ohB = append(P.tables, t6);
+      build_table(hi, 2, st.H, t6); st.t.ohC = append(P.tables, t6);
+      build_table(lo, 0, st.L, t6); st.t.olA = append(P.tables, t6);
+      build_table(lo, 1, st.L, t6); st.t.olB = append(P.tables, t6);
+      build_table(lo, 2, st.L, t6); st.t.olC = append(P.tables, t6);
+      // 16-byte vectors along n: each operand is unit-stride or broadcast there, everything aligned
+      bool vok = nl && st.Nv % vec == 0 && (st.sAn == 0 || st.sAn == 1) && (st.sBn == 0 || st.sBn == 1);
+      for (auto& l : info) {
+        if (&l == nl) continue;
+        if (l.inC && l.sC % vec != 0) vok = false;
+        if (st.sAn == 1 && l.inA && l.sA % vec != 0) vok = false;
+        if (st.sBn == 1 && l.inB && l.sB % vec != 0) vok = false;
+      }
+      st.vecw = vok ? (int)vec : 1;
+      // a long sum over a unit-stride K of the larger operand: lanes along k instead
+      const bool aBig = rhs < 0 || P.tensors[lhs].numel >= P.tensors[rhs].numel;
+      const bool kContig = aBig ? st.modeA == 2 : st.modeB == 2;
+      bool kUnit = kContig;
+      if (!kUnit && !G[kK].empty()) {  // mode flags need vector alignment; unit stride alone is enough here
+        const LabelInfo* kl = G[kK].back();
+        kUnit = aBig ? (kl->inA && kl->sA == 1) : (kl->inB && kl->sB == 1);
+      }
+      if (st.K >= 64 && kUnit) {
+        st.kernel = CTN_KERNEL_ROWDOT;
+        // persistent-style grid: at most 16 workgroups per CU, waves stride over the outputs
+        st.blocks = (int)std::min<int64_t>((outs + 3) / 4, kStreamMaxBlocks);
+      } else {
+        st.kernel = CTN_KERNEL_ELEMENT;
+        const int64_t items = st.H * st.L * ((st.Nv + st.vecw - 1) / st.vecw);
+        st.blocks = (int)std::min<int64_t>((items + 255) / 256, kStreamMaxBlocks);
+      }
     }
+    st.chain_ok = outs <= kChainMaxOut && outs * st.K <= kChainMaxWork;
     st.collapse = st.blocks > kMaxPartials;
     st.partials = st.collapse ? 1 : st.blocks;
     if (st.collapse) P.max_collapse_blocks = std::max<int64_t>(P.max_collapse_blocks, st.blocks);
@@ -323,13 +372,16 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
         gn(G[kN].begin(), G[kN].end()), gk(G[kK].begin(), G[kK].end());
     const int64_t padM = round_up(st.M, kTileM), padN = round_up(st.N, kTileN), padK = round_up(st.K, kPadK) + 2 * kPadK;  // kernels prefetch table entries two tiles ahead
     std::vector<int32_t> tb;
-    build_table(gb, 0, st.Bt, tb); st.t.obA = append(P.tables, tb);
-    build_table(gb, 1, st.Bt, tb); st.t.obB = append(P.tables, tb);
-    build_table(gb, 2, st.Bt, tb); st.t.obC = append(P.tables, tb);
-    build_table(gm, 0, padM, tb);  st.t.omA = append(P.tables, tb);
-    build_table(gm, 2, padM, tb);  st.t.omC = append(P.tables, tb);
-    build_table(gn, 1, padN, tb);  st.t.onB = append(P.tables, tb);
-    build_table(gn, 2, padN, tb);  st.t.onC = append(P.tables, tb);
+    const bool tiled = st.kernel == CTN_KERNEL_MFMA_F32 || st.kernel == CTN_KERNEL_MFMA_F64 || st.kernel == CTN_KERNEL_DOT;
+    if (tiled || st.chain_ok) {  // (batch, m, n) tables: tile kernels and the chain walker
+      build_table(gb, 0, st.Bt, tb); st.t.obA = append(P.tables, tb);
+      build_table(gb, 1, st.Bt, tb); st.t.obB = append(P.tables, tb);
+      build_table(gb, 2, st.Bt, tb); st.t.obC = append(P.tables, tb);
+      build_table(gm, 0, padM, tb);  st.t.omA = append(P.tables, tb);
+      build_table(gm, 2, padM, tb);  st.t.omC = append(P.tables, tb);
+      build_table(gn, 1, padN, tb);  st.t.onB = append(P.tables, tb);
+      build_table(gn, 2, padN, tb);  st.t.onC = append(P.tables, tb);
+    }
     build_table(gk, 0, padK, tb);  st.t.okA = append(P.tables, tb);
     build_table(gk, 1, padK, tb);  st.t.okB = append(P.tables, tb);
 
@@ -346,10 +398,8 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
   }
   // latency-bound DAGs (e.g. 1000 dependent 3x3 products): no per-step launch at all
   P.chain = d.n_steps >= 4 && d.n_steps <= kChainMaxSteps;
-  for (const Step& st : P.steps) {
-    const int64_t outs = st.Bt * st.M * st.N;
-    if (outs > kChainMaxOut || outs * st.K > kChainMaxWork) P.chain = false;
-  }
+  for (const Step& st : P.steps)
+    if (!st.chain_ok) P.chain = false;
   if (P.chain)
     for (Step& st : P.steps) { st.partials = 1; st.collapse = false; }
   P.ws_bytes_per_replica = arena.top;

@@ -21,6 +21,7 @@ constexpr int kTileN = 128;
 constexpr int kTile64 = 64;        // MFMA f64 workgroup tile
 constexpr bool kEnableMfmaF64 = true;
 constexpr int kPadK = 32;          // k-offset tables are padded to this multiple
+constexpr int kStreamMaxBlocks = 4096;  // streaming kernels: grid cap (16 workgroups per CU), threads stride
 constexpr int kChainMaxSteps = 4096;   // rescale factors of all steps live in LDS
 constexpr int64_t kChainMaxOut = 4096;  // per-step output elements
 constexpr int64_t kChainMaxWork = 1 << 16;  // per-step multiply-adds
@@ -39,6 +40,7 @@ struct Tensor {
 // offsets (in int32 entries) of one step's tables inside Plan::tables
 struct TableRefs {
   int64_t obA = 0, obB = 0, obC = 0, omA = 0, omC = 0, onB = 0, onC = 0, okA = 0, okB = 0;
+  int64_t ohA = 0, ohB = 0, ohC = 0, olA = 0, olB = 0, olC = 0;  // streaming kernels: (hi, lo) output groups
 };
 
 struct Step {
@@ -48,6 +50,11 @@ struct Step {
   int64_t Bt = 1, M = 1, N = 1, K = 1;
   bool has_k = false;  // false: pure product (no summed label)
   int modeA = 0, modeB = 0;
+  // streaming decomposition of the output index space (element / row-dot kernels): (hi, lo, n),
+  // n runs along C's unit-stride label, sAn/sBn are the operands' strides along it (0 = broadcast)
+  int64_t H = 1, L = 1, Nv = 1, sAn = 0, sBn = 0;
+  int vecw = 1;          // output elements per thread (16-byte vectors when > 1)
+  bool chain_ok = false; // small enough for the persistent chain walker
   bool cvec = false;   // 16-byte vector stores of C are valid (unit-stride column label, aligned strides)
   int blocks = 1;      // workgroups per replica
   int partials = 1;    // partial abs-sums per replica after the optional collapse pass

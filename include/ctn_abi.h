@@ -52,10 +52,12 @@ typedef enum { CTN_MEM_HOST = 0, CTN_MEM_DEVICE = 1 } ctn_memspace;
 
 /* which kernel family a step was lowered to (ctn_step_info.kernel) */
 typedef enum {
-  CTN_KERNEL_ELEMENT = 0, /* one thread per output element, K loop (hyperedge / tiny steps) */
+  CTN_KERNEL_ELEMENT = 0, /* streaming gather-multiply: one thread per 16-byte output vector, K loop
+                             (copy-tensor / hyperedge products, Khatri-Rao, traces, small-K steps) */
   CTN_KERNEL_DOT = 1,     /* one workgroup per output element, K split over lanes */
   CTN_KERNEL_MFMA_F32 = 2,/* 128x128 LDS-tiled v_mfma_f32_32x32x2_f32 GEMM, gather loads */
-  CTN_KERNEL_MFMA_F64 = 3 /* 64x64 LDS-tiled v_mfma_f64_16x16x4_f64 GEMM, gather loads */
+  CTN_KERNEL_MFMA_F64 = 3,/* 64x64 LDS-tiled v_mfma_f64_16x16x4_f64 GEMM, gather loads */
+  CTN_KERNEL_ROWDOT = 4   /* one wave per output element, lanes along a unit-stride K (GEMV-like) */
 } ctn_kernel_kind;
 
 typedef struct ctn_plan ctn_plan;
