@@ -1026,7 +1026,10 @@ static int exec_launch_all(Exec* E) {
         // vector stores need a 16-byte aligned destination: the caller's final buffer may not be
         const int vw = (s + 1 == P.n_steps && !E->outs_aligned16) ? 1 : st.vecw;
         const int64_t nq = (st.Nv + vw - 1) / vw;
-        const int u = (nq % 4 == 0) ? 4 : 1;
+        // 4 vectors per row lookup only where it pays: short K (lookup-dominated) and enough rows
+        // left to fill the chip; long-K / small steps keep one vector per thread for parallelism
+        const int64_t rows = st.H * st.L * (int64_t)R;
+        const int u = (nq % 4 == 0 && st.K <= 16 && rows * (nq / 4) >= (1 << 20)) ? 4 : 1;
         a.dNq = make_fastdiv(nq / u);
         const dim3 g(st.blocks, R), b(256);
 #define CTN_STREAM(TT, VV, UU) hipLaunchKernelGGL((k_stream<TT, VV, UU>), g, b, 0, E->stream, a)
