@@ -1,0 +1,86 @@
+"""Randomised einsum structures on the GPU vs numpy.einsum (fp64, tight tolerance).
+
+Exercises the label algebra of the planner: batch (kept+shared), free, contracted, summed-out and
+diagonal labels, extent-1 axes, arbitrary output permutations, unary steps, multi-operand paths."""
+import numpy as np
+import pytest
+
+from contractn_amd import contract
+
+pytestmark = pytest.mark.gpu
+
+LETTERS = "abcdefghij"
+
+
+def random_pair_case(rng):
+    n_lab = rng.integers(1, 7)
+    labels = list(LETTERS[:n_lab])
+    sizes = {l: int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 33])) for l in labels}
+    def term():
+        k = rng.integers(0, min(n_lab, 4) + 1)
+        t = list(rng.choice(labels, size=k, replace=False))
+        if t and rng.random() < 0.15:           # diagonal: repeat one label
+            t.insert(rng.integers(0, len(t) + 1), t[rng.integers(0, len(t))])
+        return "".join(t)
+    ta, tb = term(), term()
+    present = sorted(set(ta + tb))
+    keep = [l for l in present if rng.random() < 0.6]
+    rng.shuffle(keep)
+    return f"{ta},{tb}->{''.join(keep)}", sizes
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_pairwise_step(seed):
+    rng = np.random.default_rng(seed)
+    einstr, sizes = random_pair_case(rng)
+    lhs = einstr.split("->")[0].split(",")
+    ops = [rng.standard_normal([sizes[c] for c in t]) for t in lhs]
+    ref = np.einsum(einstr, *ops)
+    t_hat, c = contract(einstr, *ops, split_format=True)
+    got = np.asarray(t_hat) * np.exp(float(c))
+    assert got.shape == ref.shape, einstr
+    scale = max(np.max(np.abs(ref)), 1e-300)
+    assert np.max(np.abs(got - ref)) <= 1e-11 * scale, (einstr, sizes)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_network(seed):
+    """3-6 operands, random shared labels (hyperedges allowed), auto path."""
+    rng = np.random.default_rng(1000 + seed)
+    n_ops = int(rng.integers(3, 7))
+    labels = list(LETTERS[: int(rng.integers(3, 8))])
+    sizes = {l: int(rng.choice([2, 3, 4, 6])) for l in labels}
+    terms = []
+    for _ in range(n_ops):
+        k = int(rng.integers(1, min(len(labels), 4) + 1))
+        terms.append("".join(rng.choice(labels, size=k, replace=False)))
+    present = sorted(set("".join(terms)))
+    keep = [l for l in present if rng.random() < 0.35]
+    rng.shuffle(keep)
+    einstr = ",".join(terms) + "->" + "".join(keep)
+    ops = [rng.standard_normal([sizes[c] for c in t]) for t in terms]
+    ref = np.einsum(einstr, *ops)
+    t_hat, c = contract(einstr, *ops, split_format=True)
+    got = np.asarray(t_hat) * np.exp(float(c))
+    scale = max(np.max(np.abs(ref)), 1e-300)
+    assert np.max(np.abs(got - ref)) <= 1e-10 * scale, einstr
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_pairwise_step_f32_larger(seed):
+    """fp32 with extents that reach the MFMA / row-dot / vector-stream kernels."""
+    rng = np.random.default_rng(5000 + seed)
+    pool = [1, 2, 4, 8, 12, 32, 40, 64, 100, 128]
+    sizes = {l: int(rng.choice(pool)) for l in "abcde"}
+    ta = "".join(rng.choice(list("abcde"), size=int(rng.integers(1, 4)), replace=False))
+    tb = "".join(rng.choice(list("abcde"), size=int(rng.integers(1, 4)), replace=False))
+    present = sorted(set(ta + tb))
+    keep = [l for l in present if rng.random() < 0.6]
+    rng.shuffle(keep)
+    einstr = f"{ta},{tb}->{''.join(keep)}"
+    ops = [rng.standard_normal([sizes[c] for c in t]).astype(np.float32) for t in (ta, tb)]
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    t_hat, c = contract(einstr, *ops, split_format=True)
+    got = np.asarray(t_hat, dtype=np.float64) * np.exp(float(c))
+    scale = max(np.max(np.abs(ref)), 1e-300)
+    assert np.max(np.abs(got - ref)) <= 2e-4 * scale, (einstr, sizes)
