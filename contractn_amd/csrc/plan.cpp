@@ -296,10 +296,14 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
 
     // -- kernel choice
     const int64_t outs = st.Bt * st.M * st.N;
-    if (P.dtype == CTN_F32 && st.M >= 32 && st.N >= 32 && st.K >= 8) {
+    // tile kernels: both free extents >= 32, or one long (>= 128) and the other at least 8 wide - a
+    // mostly-masked MFMA tile still beats the streaming kernels by an order of magnitude there
+    const bool tileable = st.K >= 8 && ((st.M >= 32 && st.N >= 32) || (st.M >= 128 && st.N >= 8) ||
+                                        (st.N >= 128 && st.M >= 8));
+    if (P.dtype == CTN_F32 && tileable) {
       st.kernel = CTN_KERNEL_MFMA_F32;
       st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + kTileN - 1) / kTileN));
-    } else if (kEnableMfmaF64 && P.dtype == CTN_F64 && st.M >= 32 && st.N >= 32 && st.K >= 8) {
+    } else if (kEnableMfmaF64 && P.dtype == CTN_F64 && tileable) {
       st.kernel = CTN_KERNEL_MFMA_F64;
       st.blocks = (int)(st.Bt * ((st.M + kTile64 - 1) / kTile64) * ((st.N + kTile64 - 1) / kTile64));
     } else if (outs <= kMaxPartials && st.K >= 512) {
@@ -349,7 +353,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
         const LabelInfo* kl = G[kK].back();
         kUnit = aBig ? (kl->inA && kl->sA == 1) : (kl->inB && kl->sB == 1);
       }
-      if (st.K >= 64 && kUnit) {
+      if (st.K >= 256 && kUnit) {
         st.kernel = CTN_KERNEL_ROWDOT;
         // persistent-style grid: at most 16 workgroups per CU, waves stride over the outputs
         st.blocks = (int)std::min<int64_t>((outs + 3) / 4, kStreamMaxBlocks);
