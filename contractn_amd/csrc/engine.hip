@@ -361,31 +361,37 @@ __global__ __launch_bounds__(256) void k_finalize(FinalArgs f, const double* __r
 }
 
 // ---------------------------------------------------------------------------
-// K-mfma-f32: 128x128 workgroup tile, 4 waves (2x2), each wave 64x64 =
-// 2x2 v_mfma_f32_32x32x2_f32 accumulators, register-staged double-buffered LDS,
-// one barrier per k-tile.
+// K-mfma-f32: 128 x TN workgroup tile (TN = 128 or 64), 4 waves (2x2), each wave
+// 64 x TN/2 = 2 x TN/64 v_mfma_f32_32x32x2_f32 accumulators, register-staged
+// double-buffered LDS, one barrier per k-tile.  TN = 64 serves skinny products
+// (boundary absorptions of 2D grids: N = 64) where a 128-wide tile would be half masked.
 //
 // MODE (per operand): 0 scalar gather, 1 float4 along the free index (LDS image
-// [k][m]), 2 float4 along k (LDS image [m][BK+1], odd row length => conflict-free
+// [k][rows]), 2 float4 along k (LDS image [rows][BK+1], odd row length => conflict-free
 // ds_read_b32 for the MFMA fragment: lane l reads row l&31, k = 2*kk + (l>>5)).
 //
 // Latency structure: the k-offset table entries of tile t+2 are requested while
 // tile t+1's data loads are in flight and tile t is being multiplied, so no
 // load ever waits on a table lookup; global loads are unconditional (padded
-// tables keep every address in bounds) and masked with a select; LDS fragment
+// tables keep every address in bounds) and masked when written to LDS; LDS fragment
 // reads run one k-step ahead of the MFMAs that consume them.
 // ---------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = kTileM, BN = kTileN;
+constexpr int BM = kTileM;
 
-template <int MODE, int BK>
+// Stages one ROWS x BK operand tile per k-step: global -> registers -> LDS.
+template <int MODE, int BK, int ROWS>
 struct TileLoader {
-  static constexpr int NV = BM * BK / 256;                 // floats staged per thread
-  static constexpr int NT = MODE == 1 ? NV / 4 : (MODE == 2 ? 1 : NV);   // table entries per tile
+  static constexpr int NV = ROWS * BK / 256;               // floats staged per thread
+  static constexpr int VPR = ROWS / 4;                     // mode 1: float4 per k-row
+  static constexpr int RPP = 256 / VPR;                    // mode 1: k-rows covered per pass
+  static constexpr int KPP = 256 / ROWS;                   // mode 0: k-rows covered per pass
+  static constexpr int NT = MODE == 1 ? BK / RPP : (MODE == 2 ? 1 : NV);  // table entries per tile
   static constexpr int NM = MODE == 2 ? NV / 4 : 1;        // hoisted free-index offsets
   static constexpr int LDK = BK + 1;
-  static constexpr int kSize = MODE == 2 ? BM * LDK : BK * BM;
+  static constexpr int kSize = MODE == 2 ? ROWS * LDK : BK * ROWS;
+  static_assert(NV >= 4 && NT >= 1 && NM >= 1, "tile too small for 256 threads");
 
   float v[NV];
   int kofs[NT];   // k-offset table entries of the NEXT tile to load
@@ -394,7 +400,7 @@ struct TileLoader {
 
   __device__ __forceinline__ void init(const int32_t* __restrict__ om, int m0, int M, int tid) {
     if (MODE == 1) {
-      const int gm = m0 + (tid & 31) * 4;
+      const int gm = m0 + (tid % VPR) * 4;
       offm[0] = om[gm];
       okm[0] = gm < M;
     } else if (MODE == 2) {
@@ -405,7 +411,7 @@ struct TileLoader {
         okm[i] = gm < M;
       }
     } else {
-      const int gm = m0 + (tid & 127);
+      const int gm = m0 + (tid % ROWS);
       offm[0] = om[gm];
       okm[0] = gm < M;
     }
@@ -415,12 +421,12 @@ struct TileLoader {
   __device__ __forceinline__ void tab(const int32_t* __restrict__ ok, int k0, int tid) {
     if (MODE == 1) {
 #pragma unroll
-      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + (tid >> 5) + 8 * i];
+      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + tid / VPR + RPP * i];
     } else if (MODE == 2) {
       kofs[0] = ok[k0 + (tid % (BK / 4)) * 4];
     } else {
 #pragma unroll
-      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + (tid >> 7) + 2 * i];
+      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + tid / ROWS + KPP * i];
     }
   }
 
@@ -452,8 +458,9 @@ struct TileLoader {
     if (MODE == 1) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        const bool in = FULL || (okm[0] && (k0 + (tid >> 5) + 8 * i) < K);
-        *reinterpret_cast<float4*>(s + ((tid >> 5) + 8 * i) * BM + (tid & 31) * 4) =
+        const int kr = tid / VPR + RPP * i;
+        const bool in = FULL || (okm[0] && (k0 + kr) < K);
+        *reinterpret_cast<float4*>(s + kr * ROWS + (tid % VPR) * 4) =
             make_float4(in ? v[4 * i] : 0.f, in ? v[4 * i + 1] : 0.f, in ? v[4 * i + 2] : 0.f,
                         in ? v[4 * i + 3] : 0.f);
       }
@@ -469,28 +476,30 @@ struct TileLoader {
     } else {
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        const bool in = FULL || (okm[0] && (k0 + (tid >> 7) + 2 * i) < K);
-        s[((tid >> 7) + 2 * i) * BM + (tid & 127)] = in ? v[i] : 0.f;
+        const int kr = tid / ROWS + KPP * i;
+        const bool in = FULL || (okm[0] && (k0 + kr) < K);
+        s[kr * ROWS + (tid % ROWS)] = in ? v[i] : 0.f;
       }
     }
   }
 
   // LDS index of element (row, k) of the tile image
   static __device__ __forceinline__ int idx(int row, int k) {
-    return MODE == 2 ? row * LDK + k : k * BM + row;
+    return MODE == 2 ? row * LDK + k : k * ROWS + row;
   }
 };
 
-template <int MA, int MB, int BK, bool FULL>
-__device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK>& la, TileLoader<MB, BK>& lb,
+template <int MA, int MB, int BK, int TN, bool FULL>
+__device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLoader<MB, BK, TN>& lb,
                                               const float* __restrict__ A, const float* __restrict__ B,
                                               const int32_t* __restrict__ okA, const int32_t* __restrict__ okB,
-                                              int K, float* sA, float* sB, f32x16 (&acc)[2][2], int tid) {
-  using LA = TileLoader<MA, BK>;
-  using LB = TileLoader<MB, BK>;
+                                              int K, float* sA, float* sB, f32x16 (&acc)[2][TN / 64], int tid) {
+  using LA = TileLoader<MA, BK, BM>;
+  using LB = TileLoader<MB, BK, TN>;
   constexpr int SZA = LA::kSize, SZB = LB::kSize;
+  constexpr int NJ = TN / 64;  // 32-wide column blocks per wave
   const int lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * (TN / 2);
   const int l31 = lane & 31, h = lane >> 5;
 
   const int nkt = (K + BK - 1) / BK;
@@ -506,9 +515,11 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK>& la, TileLoader
 
   // per-lane LDS fragment bases (element indices)
   const int fa0 = LA::idx(wm + l31, h), fa1 = LA::idx(wm + 32 + l31, h);
-  const int fb0 = LB::idx(wn + l31, h), fb1 = LB::idx(wn + 32 + l31, h);
+  int fbx[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) fbx[j] = LB::idx(wn + j * 32 + l31, h);
   constexpr int stepA = MA == 2 ? 2 : 2 * BM;  // advance of the fragment index per k-step (k += 2)
-  constexpr int stepB = MB == 2 ? 2 : 2 * BN;
+  constexpr int stepB = MB == 2 ? 2 : 2 * TN;
 
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
@@ -522,23 +533,26 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK>& la, TileLoader
     __builtin_amdgcn_sched_barrier(0);  // global loads stay in front of the MFMA phase
     const float* cA = sA + cur * SZA;
     const float* cB = sB + cur * SZB;
-    float fa[2][2], fb[2][2];
+    float fa[2][2], fb[2][NJ];
     fa[0][0] = cA[fa0]; fa[0][1] = cA[fa1];
-    fb[0][0] = cB[fb0]; fb[0][1] = cB[fb1];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) fb[0][j] = cB[fbx[j]];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int c = kk & 1, nx = c ^ 1;
       if (kk + 1 < BK / 2) {
         fa[nx][0] = cA[fa0 + (kk + 1) * stepA]; fa[nx][1] = cA[fa1 + (kk + 1) * stepA];
-        fb[nx][0] = cB[fb0 + (kk + 1) * stepB]; fb[nx][1] = cB[fb1 + (kk + 1) * stepB];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[nx][j] = cB[fbx[j] + (kk + 1) * stepB];
       }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
       // pin the interleave: the LDS reads of step kk+1 issue ahead of the MFMAs of step kk
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
     }
     __builtin_amdgcn_sched_barrier(0);  // the staged tile is consumed only after the MFMA phase
     if (more) {
@@ -549,18 +563,21 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK>& la, TileLoader
   }
 }
 
-template <int MA, int MB, int BK>
-__global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
-  using LA = TileLoader<MA, BK>;
-  using LB = TileLoader<MB, BK>;
+// second launch-bound argument = waves per SIMD the register allocator must leave room for:
+// BK = 16 is sized for 3 workgroups per CU (<= 168 registers), BK = 32 for 2
+template <int MA, int MB, int BK, int TN>
+__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a) {
+  using LA = TileLoader<MA, BK, BM>;
+  using LB = TileLoader<MB, BK, TN>;
   constexpr int SZA = LA::kSize, SZB = LB::kSize;
-  // one LDS object: [A buf0][A buf1][B buf0][B buf1][omC 128][onC 128][red 4 doubles]
-  __shared__ __attribute__((aligned(16))) float smem[2 * SZA + 2 * SZB + BM + BN + 8];
+  constexpr int NJ = TN / 64;
+  // one LDS object: [A buf0][A buf1][B buf0][B buf1][omC 128][onC TN][red 4 doubles]
+  __shared__ __attribute__((aligned(16))) float smem[2 * SZA + 2 * SZB + BM + TN + 8];
   float* sA = smem;
   float* sB = smem + 2 * SZA;
   int* s_omC = reinterpret_cast<int*>(smem + 2 * SZA + 2 * SZB);
   int* s_onC = s_omC + BM;
-  double* red = reinterpret_cast<double*>(s_onC + BN);
+  double* red = reinterpret_cast<double*>(s_onC + TN);
 
   const int tid = threadIdx.x;
   // XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs, so give each
@@ -574,7 +591,7 @@ __global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
   const int b = t / tiles_mn;
   const int tt = t - b * tiles_mn;
   const int m0 = (tt / a.tiles_n) * BM;
-  const int n0 = (tt % a.tiles_n) * BN;
+  const int n0 = (tt % a.tiles_n) * TN;
 
   const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
   const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
@@ -585,7 +602,7 @@ __global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
   float* __restrict__ C = (float*)tp[a.idC] + a.obC[b];
 
   if (tid < BM) s_omC[tid] = a.omC[m0 + tid];
-  else s_onC[tid - BM] = a.onC[n0 + tid - BM];
+  else if (tid - BM < TN) s_onC[tid - BM] = a.onC[n0 + tid - BM];
 
   LA la;
   LB lb;
@@ -593,33 +610,35 @@ __global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
   lb.init(a.onB, n0, a.N, tid);
 
   const int lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * (TN / 2);
   const int l31 = lane & 31, h = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // FULL: the tile lies completely inside M x N and K is a multiple of BK -> no masking
-  const bool full = (m0 + BM <= a.M) && (n0 + BN <= a.N) && (a.K % BK == 0);
-  if (full) mfma_mainloop<MA, MB, BK, true>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid);
-  else mfma_mainloop<MA, MB, BK, false>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid);
+  const bool full = (m0 + BM <= a.M) && (n0 + TN <= a.N) && (a.K % BK == 0);
+  if (full) mfma_mainloop<MA, MB, BK, TN, true>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid);
+  else mfma_mainloop<MA, MB, BK, TN, false>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid);
 
   // epilogue: lazy rescale, store through the C offset tables, abs-sum partial
   const float iA = 1.0f / scA, iB = 1.0f / scB;
   float asum = 0.f;
   {
     // Stage the accumulator tile through the (now idle) operand buffers so that every thread
-    // stores whole 16-byte row segments: wide stores instead of 64 dwords per thread.  BK = 32
-    // has room for all 128 rows at once, BK = 16 (32 KiB of LDS) does two 64-row halves.
-    constexpr int NH = BK >= 32 ? 1 : 2;
+    // stores whole 16-byte row segments instead of 32*NJ dwords; two 64-row halves when the
+    // buffers cannot hold all 128 rows (BK = 16).
+    constexpr int NH = (BM * TN > 2 * SZA + 2 * SZB) ? 2 : 1;
     constexpr int ROWS = BM / NH;
-    float* sC = smem;  // [ROWS][BN]
-    const int c4 = (tid & 31) * 4;
+    constexpr int VPRC = TN / 4;          // 16-byte vectors per C row
+    constexpr int RPPC = 256 / VPRC;      // rows covered per pass
+    float* sC = smem;  // [ROWS][TN]
+    const int c4 = (tid % VPRC) * 4;
     const bool cin = n0 + c4 < a.N;  // N % 4 == 0 whenever c_vec, otherwise checked per element
     const int offn = s_onC[c4];
 #pragma unroll
@@ -628,20 +647,20 @@ __global__ __launch_bounds__(256) void k_mfma_f32(StepArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               const int row = (NH == 1 ? wm : 0) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-              sC[row * BN + wn + j * 32 + l31] = (acc[i][j][e] * iA) * iB;
+              sC[row * TN + wn + j * 32 + l31] = (acc[i][j][e] * iA) * iB;
             }
       }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < ROWS / 8; ++i) {
-        const int lrow = (tid >> 5) + 8 * i;
+      for (int i = 0; i < ROWS / RPPC; ++i) {
+        const int lrow = tid / VPRC + RPPC * i;
         const int row = hh * ROWS + lrow;
         if (m0 + row < a.M && cin) {
-          const float4 v = *reinterpret_cast<const float4*>(sC + lrow * BN + c4);
+          const float4 v = *reinterpret_cast<const float4*>(sC + lrow * TN + c4);
           float* dst = C + s_omC[row];
           if (a.c_vec) {
             *reinterpret_cast<float4*>(dst + offn) = v;
@@ -901,21 +920,21 @@ struct Exec {
   }
 };
 
-template <int MA, int BK>
+template <int MA, int BK, int TN>
 static void launch_mfma_b(int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
   switch (mb) {
-    case 1: hipLaunchKernelGGL((k_mfma_f32<MA, 1, BK>), grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((k_mfma_f32<MA, 2, BK>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((k_mfma_f32<MA, 0, BK>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((k_mfma_f32<MA, 1, BK, TN>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_mfma_f32<MA, 2, BK, TN>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_mfma_f32<MA, 0, BK, TN>), grid, dim3(256), 0, st, a); break;
   }
 }
 
-template <int BK>
+template <int BK, int TN>
 static void launch_mfma_a(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
   switch (ma) {
-    case 1: launch_mfma_b<1, BK>(mb, grid, st, a); break;
-    case 2: launch_mfma_b<2, BK>(mb, grid, st, a); break;
-    default: launch_mfma_b<0, BK>(mb, grid, st, a); break;
+    case 1: launch_mfma_b<1, BK, TN>(mb, grid, st, a); break;
+    case 2: launch_mfma_b<2, BK, TN>(mb, grid, st, a); break;
+    default: launch_mfma_b<0, BK, TN>(mb, grid, st, a); break;
   }
 }
 
@@ -933,9 +952,15 @@ static int mfma_bk(int K) {
   return K >= 2048 ? 32 : 16;
 }
 
-static void launch_mfma(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
-  if (mfma_bk(a.K) == 16) launch_mfma_a<16>(ma, mb, grid, st, a);
-  else launch_mfma_a<32>(ma, mb, grid, st, a);
+static void launch_mfma(int ma, int mb, int tile_n, dim3 grid, hipStream_t st, const StepArgs& a) {
+  const bool bk16 = mfma_bk(a.K) == 16;
+  if (tile_n == 64) {
+    if (bk16) launch_mfma_a<16, 64>(ma, mb, grid, st, a);
+    else launch_mfma_a<32, 64>(ma, mb, grid, st, a);
+  } else {
+    if (bk16) launch_mfma_a<16, 128>(ma, mb, grid, st, a);
+    else launch_mfma_a<32, 128>(ma, mb, grid, st, a);
+  }
 }
 
 static int exec_launch_all(Exec* E) {
@@ -1003,7 +1028,8 @@ static int exec_launch_all(Exec* E) {
       case CTN_KERNEL_MFMA_F32: {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
-        launch_mfma(st.modeA, st.modeB, dim3((unsigned)total), E->stream, a);
+        a.tiles_n = (int32_t)((st.N + st.tileN - 1) / st.tileN);
+        launch_mfma(st.modeA, st.modeB, st.tileN, dim3((unsigned)total), E->stream, a);
         break;
       }
       case CTN_KERNEL_MFMA_F64: {

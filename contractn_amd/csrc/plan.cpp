@@ -302,7 +302,9 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
                                         (st.N >= 128 && st.M >= 8));
     if (P.dtype == CTN_F32 && tileable) {
       st.kernel = CTN_KERNEL_MFMA_F32;
-      st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + kTileN - 1) / kTileN));
+      // 64-wide column tiles when they cover N with less padding (e.g. N = 64, 192, 320)
+      st.tileN = ((st.N + 63) / 64) * 64 < ((st.N + kTileN - 1) / kTileN) * kTileN ? 64 : kTileN;
+      st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + st.tileN - 1) / st.tileN));
     } else if (kEnableMfmaF64 && P.dtype == CTN_F64 && tileable) {
       st.kernel = CTN_KERNEL_MFMA_F64;
       st.blocks = (int)(st.Bt * ((st.M + kTile64 - 1) / kTile64) * ((st.N + kTile64 - 1) / kTile64));

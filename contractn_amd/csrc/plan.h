@@ -55,6 +55,7 @@ struct Step {
   int64_t H = 1, L = 1, Nv = 1, sAn = 0, sBn = 0;
   int vecw = 1;          // output elements per thread (16-byte vectors when > 1)
   bool chain_ok = false; // small enough for the persistent chain walker
+  int tileN = kTileN;    // MFMA f32 column tile: 128, or 64 when that wastes less padding
   bool cvec = false;   // 16-byte vector stores of C are valid (unit-stride column label, aligned strides)
   int blocks = 1;      // workgroups per replica
   int partials = 1;    // partial abs-sums per replica after the optional collapse pass
