@@ -148,3 +148,118 @@ def all_gather_combine(t_loc, c_loc, group=None, world=None):
         arr = buf.cpu().numpy()
         parts.append((arr[:-1].reshape(np.shape(t_loc)).astype(np.asarray(t_loc).dtype), arr[-1]))
     return combine_split(parts)
+
+
+def _hashable(optimize):
+    if isinstance(optimize, (str, bool)) or optimize is None:
+        return "auto" if optimize is True else optimize
+    return tuple(tuple(int(p) for p in step) for step in optimize)
+
+
+class SlicedContraction:
+    """Device-resident index slicing: every slice is one *replica* of the sliced plan.
+
+    The operands are uploaded once; a slice fixes the sliced labels, which for a tensor whose
+    sliced axes lead is just a pointer offset - so the slices of this rank run as ``R`` replicas of
+    ONE plan in one launch sequence (zero-copy), each producing ``(T_hat_s, c_s)``.  The partial
+    results are combined in split format on the host and joined across ranks with the single
+    ``all_gather`` of :func:`all_gather_combine`.
+    """
+
+    def __init__(self, einstr, operands, slice_labels, optimize="auto", rank=0, world=1, device=0,
+                 dtype=None, workspace_budget=64 << 30):
+        import torch
+
+        from . import einsum as E
+
+        self.rank, self.world = rank, world
+        shapes = [tuple(np.shape(o)) for o in operands]
+        terms, out, sizes = paths.parse_einsum_input(einstr, shapes)
+        for lab in slice_labels:
+            if lab in out or lab not in sizes:
+                raise ValueError(f"cannot slice over label '{lab}'")
+        self.slice_labels = tuple(slice_labels)
+        self.np_dtype = np.dtype(dtype or np.result_type(*[np.asarray(o).dtype for o in operands]))
+        if self.np_dtype not in (np.float32, np.float64):
+            self.np_dtype = np.dtype(np.float64)
+        tdt = torch.float32 if self.np_dtype == np.float32 else torch.float64
+        dev = torch.device("cuda", device)
+        # sliced axes first, so a slice of an operand is one contiguous block at a pointer offset
+        self.tensors, self.perm_terms, new_terms, new_shapes = [], [], [], []
+        for term, op in zip(terms, operands):
+            lead = [i for i, s in enumerate(term) if s in self.slice_labels]
+            rest = [i for i, s in enumerate(term) if s not in self.slice_labels]
+            t = torch.as_tensor(np.ascontiguousarray(np.transpose(np.asarray(op, dtype=self.np_dtype), lead + rest)),
+                                device=dev, dtype=tdt)
+            self.tensors.append(t)
+            self.perm_terms.append("".join(term[i] for i in lead))
+            new_terms.append("".join(term[i] for i in rest))
+            new_shapes.append(tuple(sizes[term[i]] for i in rest))
+        self.sliced_str = ",".join(new_terms) + "->" + out
+        self.sizes = sizes
+        ranges = [range(sizes[lab]) for lab in self.slice_labels]
+        all_slices = list(itertools.product(*ranges))
+        self.my_slices = [all_slices[i] for i in shard_range(len(all_slices), rank, world)]
+        self.out_shape = tuple(sizes[s] for s in out)
+        self.n_total = len(all_slices)
+        self.device = device
+        self.bc = None
+        self._chunks = []
+        if self.my_slices:
+            # slices run in groups of R replicas; R is bounded by the workspace the plan needs
+            probe = E._native_plan(E._contract_path(self.sliced_str, tuple(new_shapes), optimize=_hashable(optimize),
+                                                    memory_limit=None, use_blas=True),
+                                   tuple(new_shapes), self.np_dtype.name)
+            per = max(1, probe.workspace_bytes(2) - probe.workspace_bytes(1))
+            R = int(max(1, min(len(self.my_slices), workspace_budget // per)))
+            self.bc = E.BatchedContraction(self.sliced_str, new_shapes, self.np_dtype, optimize=optimize,
+                                           replicas=R, device=device)
+            item = self.np_dtype.itemsize
+            self._owned = []
+
+            def slice_ptrs(values):
+                fix = dict(zip(self.slice_labels, values))
+                ptrs = []
+                for t, lead_term, shp in zip(self.tensors, self.perm_terms, new_shapes):
+                    block = int(np.prod(shp)) if shp else 1
+                    idx = 0
+                    for s in lead_term:
+                        idx = idx * sizes[s] + fix[s]
+                    p = t.data_ptr() + idx * block * item
+                    if p % 16:  # odd-sized block: materialise an aligned copy of this slice
+                        sl = t[tuple(fix[s] for s in lead_term)].clone()
+                        self._owned.append(sl)
+                        p = sl.data_ptr()
+                    ptrs.append(p)
+                return ptrs
+
+            self.out = torch.zeros((len(self.my_slices),) + self.out_shape, device=dev, dtype=tdt)
+            self._scratch_out = torch.zeros((R,) + self.out_shape, device=dev, dtype=tdt)
+            for c0 in range(0, len(self.my_slices), R):
+                group = self.my_slices[c0:c0 + R]
+                n = len(group)
+                padded = group + [group[-1]] * (R - n)   # short last group: repeat a slice, ignore its output
+                in_ptrs = [p for values in padded for p in slice_ptrs(values)]
+                out_ptrs = [self.out[c0 + r].data_ptr() if r < n else self._scratch_out[r].data_ptr()
+                            for r in range(R)]
+                self._chunks.append((c0, n, self.bc.executor.make_enqueue(in_ptrs, out_ptrs)))
+            self.R = R
+
+    def local_result(self):
+        """Run this rank's slices group by group and combine them (split format); an exact zero
+        when the rank owns none."""
+        if self.bc is None:
+            return np.zeros(self.out_shape, dtype=self.np_dtype), np.zeros(())
+        logs = np.zeros(len(self.my_slices))
+        for c0, n, launch in self._chunks:
+            launch()
+            logs[c0:c0 + n] = self.bc.fetch_log_scale()[:n]   # waits for the group
+        t = self.out.cpu().numpy()
+        return combine_split([(t[r], logs[r]) for r in range(len(self.my_slices))])
+
+    def run(self, group=None):
+        """Contract all slices of this rank, then ONE all_gather + local combine (no collective at world 1)."""
+        t_loc, c_loc = self.local_result()
+        if self.world == 1:
+            return t_loc, c_loc
+        return all_gather_combine(t_loc, c_loc, group=group, world=self.world)

@@ -125,6 +125,41 @@ def cfg5(rows=8, cols=8, bond=8):
               {"largest_intermediate": max(i["out_numel"] for i in bc.plan.step_infos())})
 
 
+def cfg5_sliced(rows=8, cols=8, bond=8, n_bonds=3):
+    """Same network, sliced over n_bonds vertical bonds in the middle: bond**n_bonds slices run as
+    replicas of one plan (zero-copy pointer offsets) - the single-GPU leg of the multi-GPU scheme."""
+    from contractn_amd import dist
+
+    rng = np.random.default_rng(6)
+    tn = nets.peps_closed(TN, rows, cols, 2, dtype=np.float32, seed=6)
+    shapes = [tuple(bond if (d == 2 and p.ndim > 1 and ax > 0) else d for ax, d in enumerate(p.shape)) for p in tn.params]
+    ops = [(rng.standard_normal(s) / bond ** 0.5).astype(np.float32) for s in shapes]
+    path = ssa_to_linear(nets.peps_row_path(rows, cols), 2 * rows * cols)
+    terms = tn.einsum_str.split("->")[0].split(",")
+    mid = rows // 2
+    labels = tuple(next(iter(set(terms[(mid - 1) * cols + k]) & set(terms[mid * cols + k])))
+                   for k in range(2, 2 + n_bonds))
+    sc = dist.SlicedContraction(tn.einsum_str, ops, labels, optimize=path, rank=0, world=1)
+    sc.run()
+    t0 = time.perf_counter()
+    iters = 3
+    for _ in range(iters):
+        t_s, c_s = sc.run()
+    wall = (time.perf_counter() - t0) / iters
+    full_plan = E._native_plan(E._contract_path(tn.einsum_str, tuple(shapes), optimize=path, memory_limit=None,
+                                                use_blas=True), tuple(shapes), "float32")
+    print(json.dumps({"config": f"5 PEPS {rows}x{cols} D={bond} sliced over {n_bonds} bonds", "slices": sc.n_total,
+                      "ms_per_contraction": round(wall * 1e3, 3),
+                      "flop_sliced_total": sc.bc.plan.flops * sc.n_total, "flop_unsliced": full_plan.flops,
+                      "tflops_sliced": round(sc.bc.plan.flops * sc.n_total / wall / 1e12, 2),
+                      "result": [float(t_s), float(c_s)]}), flush=True)
+    # the unsliced answer for the same tensors
+    import torch
+    bc = E.BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=1)
+    outs, logs = bc.run_host([ops])
+    print(json.dumps({"unsliced_result": [float(outs[0]), float(logs[0])]}), flush=True)
+
+
 def cfg12():
     for name, build, dtype in (("1 copy node order 101", 1, np.float64), ("2 chain 1000x(3x3)", 2, np.float64)):
         tn = TN()
@@ -173,3 +208,5 @@ if __name__ == "__main__":
         cfg4()
     if "cfg5" in which:
         cfg5(8, 8, 8)
+    if "cfg5s" in which:
+        cfg5_sliced(8, 8, 8, 3)
