@@ -71,6 +71,7 @@ struct StepArgs {
   const int32_t *ohA, *ohB, *ohC, *olA, *olB, *olC;
   int32_t H, L, Nv, sAn, sBn;
   FastDiv dNq, dL, dNv;  // divisors: vectors per row, lo extent, n extent
+  unsigned long long* dbg;  // CTN_STAMPS builds only: 4 cycle stamps per MFMA tile (else unused, null)
 };
 
 struct FinalArgs {
@@ -493,7 +494,8 @@ template <int MA, int MB, int BK, int TN, bool FULL>
 __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLoader<MB, BK, TN>& lb,
                                               const float* __restrict__ A, const float* __restrict__ B,
                                               const int32_t* __restrict__ okA, const int32_t* __restrict__ okB,
-                                              int K, float* sA, float* sB, f32x16 (&acc)[2][TN / 64], int tid) {
+                                              int K, float* sA, float* sB, f32x16 (&acc)[2][TN / 64], int tid,
+                                              unsigned long long* dbg1) {
   using LA = TileLoader<MA, BK, BM>;
   using LB = TileLoader<MB, BK, TN>;
   constexpr int SZA = LA::kSize, SZB = LB::kSize;
@@ -512,6 +514,9 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLo
   la.template store<FULL>(sA, 0, K, tid);
   lb.template store<FULL>(sB, 0, K, tid);
   __syncthreads();
+#ifdef CTN_STAMPS
+  if (dbg1 && tid == 0) *dbg1 = __builtin_amdgcn_s_memtime();
+#endif
 
   // per-lane LDS fragment bases (element indices)
   const int fa0 = LA::idx(wm + l31, h), fa1 = LA::idx(wm + 32 + l31, h);
@@ -593,6 +598,9 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   const int m0 = (tt / a.tiles_n) * BM;
   const int n0 = (tt % a.tiles_n) * TN;
 
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 0] = __builtin_amdgcn_s_memtime();
+#endif
   const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
   const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
 
@@ -621,10 +629,18 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+#ifdef CTN_STAMPS
+  unsigned long long* stamp1 = a.dbg ? a.dbg + (size_t)pid * 4 + 1 : nullptr;
+#else
+  unsigned long long* stamp1 = nullptr;
+#endif
   // FULL: the tile lies completely inside M x N and K is a multiple of BK -> no masking
   const bool full = (m0 + BM <= a.M) && (n0 + TN <= a.N) && (a.K % BK == 0);
-  if (full) mfma_mainloop<MA, MB, BK, TN, true>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid);
-  else mfma_mainloop<MA, MB, BK, TN, false>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid);
+  if (full) mfma_mainloop<MA, MB, BK, TN, true>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
+  else mfma_mainloop<MA, MB, BK, TN, false>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 2] = __builtin_amdgcn_s_memtime();
+#endif
 
   // epilogue: lazy rescale, store through the C offset tables, abs-sum partial
   const float iA = 1.0f / scA, iB = 1.0f / scB;
@@ -681,6 +697,9 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   }
   const double tot = block_sum((double)asum, red);
   if (tid == 0) a.partC[(size_t)r * a.partC_stride + t] = tot;
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 3] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -885,6 +904,7 @@ struct Exec {
   bool own_stream = false;
   int R = 1;
   int n_tensors = 0;
+  int n_cu = 256;
   char* d_ws = nullptr;
   int32_t* d_tables = nullptr;
   void** d_ptrs = nullptr;
@@ -896,6 +916,8 @@ struct Exec {
   double* d_resc = nullptr;
   double* d_logs = nullptr;
   ChainStep* d_chain = nullptr;
+  unsigned long long* d_dbg = nullptr;  // CTN_DEBUG_STAMPS=<file>: stamps of the LAST MFMA launch
+  size_t dbg_tiles = 0;
   char* h_pack = nullptr;       // pinned host bounce buffer for many-small-operand staging
   size_t h_pack_bytes = 0;
   bool outs_aligned16 = true;
@@ -1013,6 +1035,7 @@ static int exec_launch_all(Exec* E) {
     a.blocks_per_replica = st.blocks;
     a.R = R;
     a.c_vec = (st.cvec && (s + 1 < P.n_steps || E->outs_aligned16)) ? 1 : 0;
+    a.dbg = nullptr;
     a.ohA = T + st.t.ohA; a.ohB = T + st.t.ohB; a.ohC = T + st.t.ohC;
     a.olA = T + st.t.olA; a.olB = T + st.t.olB; a.olC = T + st.t.olC;
     a.H = (int32_t)st.H; a.L = (int32_t)st.L; a.Nv = (int32_t)st.Nv;
@@ -1029,6 +1052,14 @@ static int exec_launch_all(Exec* E) {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
         a.tiles_n = (int32_t)((st.N + st.tileN - 1) / st.tileN);
+        if (getenv("CTN_DEBUG_STAMPS")) {
+          if (E->dbg_tiles < (size_t)total) {
+            if (E->d_dbg) (void)hipFree(E->d_dbg);
+            HIPCHECK(hipMalloc((void**)&E->d_dbg, (size_t)total * 32));
+            E->dbg_tiles = (size_t)total;
+          }
+          a.dbg = E->d_dbg;
+        }
         launch_mfma(st.modeA, st.modeB, st.tileN, dim3((unsigned)total), E->stream, a);
         break;
       }
@@ -1228,11 +1259,13 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   if (rc != CTN_OK) return rc;
   if (device < 0 || device >= ndev) { g_err = "device index out of range"; return CTN_INVALID_ARG; }
   HIPCHECK(hipSetDevice(device));
+  int n_cu = 256;
+  (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
   ctn_exec* x = new (std::nothrow) ctn_exec();
   if (!x) { g_err = "out of host memory"; return CTN_OOM; }
   Exec& E = x->e;
   const Plan& P = plan->p;
-  E.plan = &P; E.device = device; E.R = replicas;
+  E.plan = &P; E.device = device; E.R = replicas; E.n_cu = n_cu > 0 ? n_cu : 256;
   E.n_tensors = P.n_inputs + P.n_steps + 1;
   auto fail = [&](int code) { delete x; return code; };
 #define HIPCHECK_X(expr)                                                        \
@@ -1314,6 +1347,14 @@ int ctn_exec_enqueue(ctn_exec* exec, const void* const* dev_inputs, void* const*
 int ctn_exec_synchronize(ctn_exec* exec) {
   if (!exec) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
   HIPCHECK(hipStreamSynchronize(exec->e.stream));
+  if (const char* path = getenv("CTN_DEBUG_STAMPS")) {  // development only: dump the last MFMA launch's stamps
+    Exec* E = &exec->e;
+    if (E->d_dbg && E->dbg_tiles) {
+      std::vector<unsigned long long> h(E->dbg_tiles * 4);
+      HIPCHECK(hipMemcpy(h.data(), E->d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
+  }
   return CTN_OK;
 }
 
