@@ -231,6 +231,8 @@ def _run_torch(plan, operands, dtype):
         return torch.from_numpy(outs[0]), torch.tensor(float(log_scale), dtype=tdt)
     dev = operands[0].device
     ops = [o.to(device=dev, dtype=tdt).contiguous() for o in operands]
+    # views into a larger storage may start at an odd offset: vector loads need 16-byte alignment
+    ops = [o.clone() if o.data_ptr() % 16 else o for o in ops]
     out = torch.empty(plan.out_shape, dtype=tdt, device=dev)
     cache = plan.__dict__.setdefault("_torch_executors", {})
     stream = torch.cuda.current_stream(dev).cuda_stream

@@ -136,3 +136,51 @@ def test_single_step_shapes_vs_numpy(dtype, tol, einstr, shapes):
     assert got.shape == ref.shape
     assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)) * 10
     assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-5  # stabilised: mean |T| == 1
+
+
+def test_dtype_promotion_follows_reference_table():
+    """ints and mixed precisions compute in float64; float32 stays float32."""
+    a, b = np.arange(6).reshape(2, 3), np.arange(12).reshape(3, 4)
+    t, c = contract("ab,bc->ac", a, b, split_format=True)
+    assert t.dtype == np.float64
+    np.testing.assert_allclose(t * np.exp(c), a @ b, rtol=1e-13)
+    t, c = contract("ab,bc->ac", a.astype(np.float32), b.astype(np.float64), split_format=True)
+    assert t.dtype == np.float64
+    t, c = contract("ab,bc->ac", a.astype(np.float32), b.astype(np.float32), split_format=True)
+    assert t.dtype == np.float32 and c.dtype == np.float64
+    out = contract("ab,bc->ac", a.astype(np.float32), b.astype(np.float32))
+    assert out.dtype == np.float64  # float32 tensor times the 0-d float64 register (reference behaviour)
+    t, _ = contract("ab,bc->ac", a, b, split_format=True, dtype=np.float32)
+    assert t.dtype == np.float32
+
+
+def test_non_contiguous_and_list_paths():
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((5, 7)).T            # Fortran-ordered view
+    b = rng.standard_normal((10, 5))[::2]        # strided rows
+    c = rng.standard_normal((5, 4))
+    ref = np.einsum("ab,cb,cd->ad", a, b, c)
+    for path in ([(0, 1), (0, 1)], ((1, 2), (0, 1)), "greedy", "optimal", True):
+        out = contract("ab,cb,cd->ad", a, b, c, optimize=path)
+        np.testing.assert_allclose(out, ref, rtol=1e-12)
+    out = contract("ab,cb,cd->ad", a, b, c, memory_limit=None, use_blas=False, order="K", casting="safe")
+    np.testing.assert_allclose(out, ref, rtol=1e-12)
+    with pytest.raises(NotImplementedError):
+        contract("ab,bc->ac", a, a.T, backend="jax")
+
+
+def test_make_contract_fun_accepts_new_params_each_call():
+    """reference ctn.py:349-387 / SURVEY App. C-13: the compiled closure takes fresh tensors."""
+    from contractn_amd import TN
+
+    rng = np.random.default_rng(4)
+    tn = TN()
+    x = tn.add_dense_node(rng.standard_normal((6, 5)))
+    y = tn.add_dense_node(rng.standard_normal((5, 3)))
+    tn.connect_nodes(x, y, 1, 0)
+    fun = tn.make_contract_fun()
+    for _ in range(3):
+        p = (rng.standard_normal((6, 5)), rng.standard_normal((5, 3)))
+        np.testing.assert_allclose(fun(p, ()), p[0] @ p[1], rtol=1e-12)
+    x.tensor = np.ones((6, 5))
+    np.testing.assert_allclose(tn.contract(), np.ones((6, 5)) @ tn.params[1], rtol=1e-12)
