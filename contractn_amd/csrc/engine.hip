@@ -646,37 +646,34 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   const float iA = 1.0f / scA, iB = 1.0f / scB;
   float asum = 0.f;
   {
-    // Stage the accumulator tile through the (now idle) operand buffers so that every thread
-    // stores whole 16-byte row segments instead of 32*NJ dwords; two 64-row halves when the
-    // buffers cannot hold all 128 rows (BK = 16).
-    constexpr int NH = (BM * TN > 2 * SZA + 2 * SZB) ? 2 : 1;
-    constexpr int ROWS = BM / NH;
-    constexpr int VPRC = TN / 4;          // 16-byte vectors per C row
-    constexpr int RPPC = 256 / VPRC;      // rows covered per pass
-    float* sC = smem;  // [ROWS][TN]
-    const int c4 = (tid % VPRC) * 4;
-    const bool cin = n0 + c4 < a.N;  // N % 4 == 0 whenever c_vec, otherwise checked per element
-    const int offn = s_onC[c4];
+    // Each WAVE stages its own 64 x TN/2 accumulator block through its quarter of the (now idle)
+    // operand buffers, 32 rows at a time, and stores whole 16-byte row segments (4-8 rows of
+    // 128-256 contiguous bytes per store instruction).  No workgroup barrier is involved: LDS
+    // operations of one wave execute in order, so the write -> read hand-off is wave-local.
+    constexpr int WT = TN / 2;                       // columns owned by a wave
+    constexpr int LDSW = ((2 * SZA + 2 * SZB) / 4) & ~3;  // floats of LDS per wave (16-byte aligned)
+    static_assert(LDSW >= 32 * WT, "per-wave staging area too small");
+    constexpr int VW = WT / 4;                       // 16-byte vectors per row
+    constexpr int RPI = 64 / VW;                     // rows covered by one wave-wide vector access
+    float* wC = smem + w * LDSW;                     // [32][WT]
+    const int c4 = (lane % VW) * 4;
+    const int gcol = wn + c4;
+    const bool cin = n0 + gcol < a.N;  // N % 4 == 0 whenever c_vec, otherwise checked per element
+    const int offn = s_onC[gcol];
 #pragma unroll
-    for (int hh = 0; hh < NH; ++hh) {
-      if (NH == 1 || (w >> 1) == hh) {
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j)
+        for (int e = 0; e < 16; ++e)
+          wC[((e & 3) + 8 * (e >> 2) + 4 * h) * WT + j * 32 + l31] = (acc[i][j][e] * iA) * iB;
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int row = (NH == 1 ? wm : 0) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-              sC[row * TN + wn + j * 32 + l31] = (acc[i][j][e] * iA) * iB;
-            }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < ROWS / RPPC; ++i) {
-        const int lrow = tid / VPRC + RPPC * i;
-        const int row = hh * ROWS + lrow;
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int lrow = it * RPI + lane / VW;
+        const int row = wm + i * 32 + lrow;
+        const float4 v = *reinterpret_cast<const float4*>(wC + lrow * WT + c4);
         if (m0 + row < a.M && cin) {
-          const float4 v = *reinterpret_cast<const float4*>(sC + lrow * TN + c4);
           float* dst = C + s_omC[row];
           if (a.c_vec) {
             *reinterpret_cast<float4*>(dst + offn) = v;
@@ -685,14 +682,14 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
             const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (n0 + c4 + q < a.N) {
-                dst[s_onC[c4 + q]] = vv[q];
+              if (n0 + gcol + q < a.N) {
+                dst[s_onC[gcol + q]] = vv[q];
                 asum += fabsf(vv[q]);
               }
           }
         }
       }
-      if (hh + 1 < NH) __syncthreads();
+      __builtin_amdgcn_wave_barrier();
     }
   }
   const double tot = block_sum((double)asum, red);
