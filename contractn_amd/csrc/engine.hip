@@ -26,859 +26,11 @@
 
 #include "plan.h"
 
+#include "kernel_args.h"
+#include "kernels_mfma.h"
+#include "kernels_stream.h"
+
 namespace ctn {
-
-// ---------------------------------------------------------------------------
-// kernel arguments
-// ---------------------------------------------------------------------------
-// n / d for 0 <= n < 2^31 by multiply-shift (host-precomputed): exact, ~5 instructions instead of
-// the ~40 (32-bit) / ~100 (64-bit) of a hardware-less integer division.
-struct FastDiv {
-  uint64_t M;
-  uint32_t d;
-  int32_t k;
-  __device__ __forceinline__ uint32_t div(uint32_t n) const { return (uint32_t)(((uint64_t)n * M) >> k); }
-};
-static FastDiv make_fastdiv(int64_t d64) {
-  FastDiv f;
-  const uint32_t d = (uint32_t)std::max<int64_t>(d64, 1);
-  int lg = 0;
-  while ((1ull << lg) < d) ++lg;
-  f.d = d;
-  f.k = 31 + lg;
-  f.M = ((1ull << f.k) / d) + 1;   // n * M < 2^31 * 2^(32) fits in 64 bits; exact for n < 2^31
-  if (d == 1) { f.M = 1; f.k = 0; }
-  return f;
-}
-
-struct StepArgs {
-  const int32_t *obA, *obB, *obC, *omA, *omC, *onB, *onC, *okA, *okB;
-  void* const* ptrs;    // [R][n_tensors] base pointer of every tensor of every replica
-  const double* partA;  // [R][64] abs-sum partials of A's producer step, nullptr for inputs
-  const double* partB;
-  double* partC;        // [R][partC_stride] where this step's partials go
-  double numelA, numelB;
-  double min_norm;
-  int32_t Bt, M, N, K;
-  int32_t idA, idB, idC, n_tensors;
-  int32_t PA, PB;
-  int32_t partC_stride;
-  int32_t tiles_m, tiles_n;
-  int32_t blocks_per_replica;
-  int32_t R;
-  int32_t c_vec;  // float4 stores of C allowed
-  // streaming kernels: output index = (hi, lo, n); n along C's unit-stride label
-  const int32_t *ohA, *ohB, *ohC, *olA, *olB, *olC;
-  int32_t H, L, Nv, sAn, sBn;
-  FastDiv dNq, dL, dNv;  // divisors: vectors per row, lo extent, n extent
-  unsigned long long* dbg;  // CTN_STAMPS builds only: 4 cycle stamps per MFMA tile (else unused, null)
-};
-
-struct FinalArgs {
-  void* const* ptrs;
-  const double* partials;   // [n_steps][R][64]
-  const int32_t* stepP;     // [n_steps] partial count of each step
-  const double* stepNumel;  // [n_steps] numel of each step's output
-  double* log_scale;        // [R]
-  double* rescales;         // [R][n_steps]
-  double min_norm;
-  int64_t out_numel;
-  int32_t n_steps, R, id_out, n_tensors, stabilize;
-};
-
-// ---------------------------------------------------------------------------
-// device helpers
-// ---------------------------------------------------------------------------
-// Rescale factor of a tensor from its producer's partial sums (reference
-// einsum.py:97-102: norm = sum|T|, rescale = norm / numel, applied iff
-// norm > min_norm).  All 64 lanes of the calling wave must be active.
-template <typename T>
-__device__ __forceinline__ T producer_scale(const double* part, int P, double numel, double min_norm,
-                                            int r, bool* cond_out = nullptr) {
-  if (part == nullptr) {
-    if (cond_out) *cond_out = false;
-    return (T)1;
-  }
-  const int lane = threadIdx.x & 63;
-  double v = lane < P ? part[(size_t)r * kMaxPartials + lane] : 0.0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  const T norm = (T)v;
-  const bool cond = norm > (T)min_norm;
-  if (cond_out) *cond_out = cond;
-  return cond ? norm / (T)numel : (T)1;
-}
-
-// Sum over the workgroup in a fixed order; result valid in every thread.
-__device__ __forceinline__ double block_sum(double v, double* red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  const int w = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[w] = v;
-  __syncthreads();
-  double t = 0;
-  const int nw = (blockDim.x + 63) >> 6;
-  for (int i = 0; i < nw; ++i) t += red[i];
-  return t;
-}
-
-// ---------------------------------------------------------------------------
-// K-element ("stream"): copy-tensor / hyperedge products, Khatri-Rao, Hadamard, traces, small-K
-// steps.  HBM-bound gather-multiply: the output index space is (hi, lo, n) with n running along C's
-// unit-stride label; one thread produces V consecutive n (one 16-byte store), consecutive lanes
-// consecutive vectors, so C is written - and every operand that is unit-stride along n is read -
-// in full cache lines; an operand that does not carry the label is a per-thread broadcast.  No
-// identity tensor exists anywhere: a copy tensor is only the shared (hi/lo/n) index.
-// Operands are divided by their producer's rescale on load, exactly like the reference's
-// stabilize() output feeding the next step: bit-identical when the K sum is exact.
-// ---------------------------------------------------------------------------
-template <typename T, int V>
-struct VecOf;
-template <> struct VecOf<float, 4> { typedef float4 type; };
-template <> struct VecOf<double, 2> { typedef double2 type; };
-template <typename T> struct VecOf<T, 1> { typedef T type; };
-
-template <typename T, int V>
-__device__ __forceinline__ void load_vec(const T* __restrict__ p, int stride_n, T (&out)[V]) {
-  if constexpr (V == 1) {
-    out[0] = p[0];
-  } else {
-    if (stride_n == 0) {
-      const T x = p[0];
-#pragma unroll
-      for (int v = 0; v < V; ++v) out[v] = x;
-    } else {
-      typedef typename VecOf<T, V>::type VT;
-      const VT x = *reinterpret_cast<const VT*>(p);
-      const T* e = reinterpret_cast<const T*>(&x);
-#pragma unroll
-      for (int v = 0; v < V; ++v) out[v] = e[v];
-    }
-  }
-}
-
-template <typename T, int V, int U>
-__global__ __launch_bounds__(256) void k_stream(StepArgs a) {
-  __shared__ double red[4];
-  const int r = blockIdx.y;
-  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
-  const bool divA = sA != (T)1, divB = sB != (T)1;
-  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
-  const T* __restrict__ A = (const T*)tp[a.idA];
-  const T* __restrict__ B = (const T*)tp[a.idB];
-  T* __restrict__ C = (T*)tp[a.idC];
-  // one item = U vectors of V elements of one output row (hi, lo): columns c, c + S, ..., c + (U-1) S
-  // with S = vectors per row / U, so the row's table lookups and broadcast operands are paid once
-  // per U*V outputs while every store instruction of a wave still covers a contiguous segment.
-  const uint32_t nq_per = (uint32_t)((a.Nv + V - 1) / V);
-  const uint32_t S = nq_per / U;                 // U divides nq_per (checked on the host)
-  const uint32_t items = (uint32_t)a.H * (uint32_t)a.L * S;  // < 2^31
-  const FastDiv dq = a.dNq;                      // divisor S
-  const bool kone = a.K == 1;                    // pure product: k-offset tables hold a single 0
-  double absv = 0;
-  const uint32_t stride = gridDim.x * 256u;
-  for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += stride) {
-    const uint32_t row = dq.div(it);
-    const int c0 = (int)(it - row * S) * V;
-    const int h = (int)a.dL.div(row);
-    const int l = (int)(row - (uint32_t)h * (uint32_t)a.L);
-    const T* pa = A + a.ohA[h] + a.olA[l] + c0 * a.sAn;
-    const T* pb = B + a.ohB[h] + a.olB[l] + c0 * a.sBn;
-    T* pc = C + (size_t)row * a.Nv + c0;         // C is contiguous in (hi, lo, n) order
-    T acc[U][V];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int v = 0; v < V; ++v) acc[u][v] = 0;
-    const int stepA = (int)S * V * a.sAn, stepB = (int)S * V * a.sBn;
-    for (int k = 0; k < a.K; ++k) {
-      const int ka = kone ? 0 : a.okA[k], kb = kone ? 0 : a.okB[k];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        T av[V], bv[V];
-        load_vec<T, V>(pa + ka + u * stepA, a.sAn, av);
-        load_vec<T, V>(pb + kb + u * stepB, a.sBn, bv);
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-          const T x = divA ? av[v] / sA : av[v];
-          const T y = divB ? bv[v] / sB : bv[v];
-          acc[u][v] = fma(x, y, acc[u][v]);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if constexpr (V == 1) {
-        pc[u * S] = acc[u][0];
-      } else {
-        typedef typename VecOf<T, V>::type VT;
-        VT o;
-        T* e = reinterpret_cast<T*>(&o);
-#pragma unroll
-        for (int v = 0; v < V; ++v) e[v] = acc[u][v];
-        *reinterpret_cast<VT*>(pc + u * S * V) = o;
-      }
-      T part = 0;
-#pragma unroll
-      for (int v = 0; v < V; ++v) part += fabs(acc[u][v]);
-      absv += (double)part;
-    }
-  }
-  const double tot = block_sum(absv, red);
-  if (threadIdx.x == 0) a.partC[(size_t)r * a.partC_stride + blockIdx.x] = tot;
-}
-
-// ---------------------------------------------------------------------------
-// K-rowdot: one WAVE per output element, the 64 lanes stride a unit-stride K (coalesced
-// 256-byte reads), xor-butterfly reduction.  GEMV / batched-dot shaped steps.
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_rowdot(StepArgs a) {
-  __shared__ double red[4];
-  const int r = blockIdx.y;
-  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
-  const bool divA = sA != (T)1, divB = sB != (T)1;
-  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
-  const T* __restrict__ A = (const T*)tp[a.idA];
-  const T* __restrict__ B = (const T*)tp[a.idB];
-  T* __restrict__ C = (T*)tp[a.idC];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t outs = (uint32_t)a.H * (uint32_t)a.L * (uint32_t)a.Nv;
-  double mine = 0;
-  for (uint32_t o = blockIdx.x * 4u + w; o < outs; o += gridDim.x * 4u) {  // wave-uniform
-    const uint32_t o2 = a.dNv.div(o);
-    const int n = (int)(o - o2 * (uint32_t)a.Nv);
-    const int h = (int)a.dL.div(o2);
-    const int l = (int)(o2 - (uint32_t)h * (uint32_t)a.L);
-    const T* pa = A + a.ohA[h] + a.olA[l] + (int64_t)n * a.sAn;
-    const T* pb = B + a.ohB[h] + a.olB[l] + (int64_t)n * a.sBn;
-    T acc0 = 0, acc1 = 0;
-    int k = lane;
-    for (; k + 64 < a.K; k += 128) {
-      const T x0 = pa[a.okA[k]], y0 = pb[a.okB[k]];
-      const T x1 = pa[a.okA[k + 64]], y1 = pb[a.okB[k + 64]];
-      acc0 = fma(divA ? x0 / sA : x0, divB ? y0 / sB : y0, acc0);
-      acc1 = fma(divA ? x1 / sA : x1, divB ? y1 / sB : y1, acc1);
-    }
-    if (k < a.K) {
-      const T x0 = pa[a.okA[k]], y0 = pb[a.okB[k]];
-      acc0 = fma(divA ? x0 / sA : x0, divB ? y0 / sB : y0, acc0);
-    }
-    double v = (double)acc0 + (double)acc1;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    const T res = (T)v;
-    if (lane == 0) C[a.ohC[h] + a.olC[l] + n] = res;
-    mine += (double)fabs(res);
-  }
-  if (lane == 0) red[w] = mine;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    a.partC[(size_t)r * a.partC_stride + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
-}
-
-// ---------------------------------------------------------------------------
-// K-dot: one workgroup per output element, K split over 256 lanes.
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_dot(StepArgs a) {
-  __shared__ double red[4];
-  const int r = blockIdx.y;
-  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
-  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
-  const T* __restrict__ A = (const T*)tp[a.idA];
-  const T* __restrict__ B = (const T*)tp[a.idB];
-  T* __restrict__ C = (T*)tp[a.idC];
-  const int o = blockIdx.x;
-  const int n = o % a.N;
-  const int q = o / a.N;
-  const int m = q % a.M;
-  const int b = q / a.M;
-  const T* pa = A + a.obA[b] + a.omA[m];
-  const T* pb = B + a.obB[b] + a.onB[n];
-  T acc = 0;
-  for (int k = threadIdx.x; k < a.K; k += 256) acc = fma(pa[a.okA[k]] / sA, pb[a.okB[k]] / sB, acc);
-  const T tot = (T)block_sum((double)acc, red);
-  if (threadIdx.x == 0) {
-    const T v = tot;
-    C[a.obC[b] + a.omC[m] + a.onC[n]] = v;
-    a.partC[(size_t)r * a.partC_stride + o] = (double)fabs(v);
-  }
-}
-
-// Collapse > 64 per-workgroup partials into one, in a fixed order.
-__global__ __launch_bounds__(256) void k_collapse(const double* scratch, int blocks, double* part) {
-  __shared__ double red[4];
-  const int r = blockIdx.x;
-  const double* src = scratch + (size_t)r * blocks;
-  double v = 0;
-  for (int i = threadIdx.x; i < blocks; i += 256) v += src[i];
-  const double tot = block_sum(v, red);
-  if (threadIdx.x == 0) part[(size_t)r * kMaxPartials] = tot;
-}
-
-// ---------------------------------------------------------------------------
-// Finishing passes.  k_scales: one wave per (step, replica) turns the step's partials into its
-// rescale factor (0.0 = not rescaled) and log(rescale) evaluated in the tensor dtype
-// (reference einsum.py:97-106).  k_finalize: normalise the final tensor and sum the logs.
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_scales(FinalArgs f, double* __restrict__ logs) {
-  const int r = blockIdx.y;
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= f.n_steps) return;  // whole wave exits together
-  bool cond = false;
-  T sc = (T)1;
-  if (f.stabilize)
-    sc = producer_scale<T>(f.partials + (size_t)s * f.R * kMaxPartials, f.stepP[s], f.stepNumel[s],
-                           f.min_norm, r, &cond);
-  if ((threadIdx.x & 63) == 0) {
-    f.rescales[(size_t)r * f.n_steps + s] = cond ? (double)sc : 0.0;
-    logs[(size_t)r * f.n_steps + s] = cond ? (double)log(sc) : 0.0;
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_finalize(FinalArgs f, const double* __restrict__ logs) {
-  __shared__ double red[4];
-  const int r = blockIdx.y;
-  if (blockIdx.x == 0) {
-    double v = 0;
-    for (int s = threadIdx.x; s < f.n_steps; s += 256) v += logs[(size_t)r * f.n_steps + s];
-    const double tot = block_sum(v, red);
-    if (threadIdx.x == 0) f.log_scale[r] = tot;
-  }
-  if (!f.stabilize) return;
-  const double rl = f.rescales[(size_t)r * f.n_steps + f.n_steps - 1];
-  if (rl == 0.0) return;  // last step was not rescaled (norm <= min_norm): tensor unchanged
-  const T s_last = (T)rl;
-  T* out = (T*)f.ptrs[(size_t)r * f.n_tensors + f.id_out];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < f.out_numel; i += (int64_t)gridDim.x * 256)
-    out[i] = out[i] / s_last;
-}
-
-// ---------------------------------------------------------------------------
-// K-mfma-f32: 128 x TN workgroup tile (TN = 128 or 64), 4 waves (2x2), each wave
-// 64 x TN/2 = 2 x TN/64 v_mfma_f32_32x32x2_f32 accumulators, register-staged
-// double-buffered LDS, one barrier per k-tile.  TN = 64 serves skinny products
-// (boundary absorptions of 2D grids: N = 64) where a 128-wide tile would be half masked.
-//
-// MODE (per operand): 0 scalar gather, 1 float4 along the free index (LDS image
-// [k][rows]), 2 float4 along k (LDS image [rows][BK+1], odd row length => conflict-free
-// ds_read_b32 for the MFMA fragment: lane l reads row l&31, k = 2*kk + (l>>5)).
-//
-// Latency structure: the k-offset table entries of tile t+2 are requested while
-// tile t+1's data loads are in flight and tile t is being multiplied, so no
-// load ever waits on a table lookup; global loads are unconditional (padded
-// tables keep every address in bounds) and masked when written to LDS; LDS fragment
-// reads run one k-step ahead of the MFMAs that consume them.
-// ---------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = kTileM;
-
-// Stages one ROWS x BK operand tile per k-step: global -> registers -> LDS.
-template <int MODE, int BK, int ROWS>
-struct TileLoader {
-  static constexpr int NV = ROWS * BK / 256;               // floats staged per thread
-  static constexpr int VPR = ROWS / 4;                     // mode 1: float4 per k-row
-  static constexpr int RPP = 256 / VPR;                    // mode 1: k-rows covered per pass
-  static constexpr int KPP = 256 / ROWS;                   // mode 0: k-rows covered per pass
-  static constexpr int NT = MODE == 1 ? BK / RPP : (MODE == 2 ? 1 : NV);  // table entries per tile
-  static constexpr int NM = MODE == 2 ? NV / 4 : 1;        // hoisted free-index offsets
-  static constexpr int LDK = BK + 1;
-  static constexpr int kSize = MODE == 2 ? ROWS * LDK : BK * ROWS;
-  static_assert(NV >= 4 && NT >= 1 && NM >= 1, "tile too small for 256 threads");
-
-  float v[NV];
-  int kofs[NT];   // k-offset table entries of the NEXT tile to load
-  int offm[NM];
-  bool okm[NM];
-
-  __device__ __forceinline__ void init(const int32_t* __restrict__ om, int m0, int M, int tid) {
-    if (MODE == 1) {
-      const int gm = m0 + (tid % VPR) * 4;
-      offm[0] = om[gm];
-      okm[0] = gm < M;
-    } else if (MODE == 2) {
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        const int gm = m0 + ((tid + i * 256) / (BK / 4));
-        offm[i] = om[gm];
-        okm[i] = gm < M;
-      }
-    } else {
-      const int gm = m0 + (tid % ROWS);
-      offm[0] = om[gm];
-      okm[0] = gm < M;
-    }
-  }
-
-  // request the table entries this thread needs for the tile starting at k0 (table is padded)
-  __device__ __forceinline__ void tab(const int32_t* __restrict__ ok, int k0, int tid) {
-    if (MODE == 1) {
-#pragma unroll
-      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + tid / VPR + RPP * i];
-    } else if (MODE == 2) {
-      kofs[0] = ok[k0 + (tid % (BK / 4)) * 4];
-    } else {
-#pragma unroll
-      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + tid / ROWS + KPP * i];
-    }
-  }
-
-  // issue the global loads of the tile using the entries fetched by the previous tab().
-  // Unconditional: padded tables keep every address inside the tensor; out-of-range rows and
-  // k are zeroed later, in store(), so nothing here waits on the data.
-  __device__ __forceinline__ void load(const float* __restrict__ base) {
-    if (MODE == 1) {
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const float4 x = *reinterpret_cast<const float4*>(base + offm[0] + kofs[i]);
-        v[4 * i + 0] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
-      }
-    } else if (MODE == 2) {
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        const float4 x = *reinterpret_cast<const float4*>(base + offm[i] + kofs[0]);
-        v[4 * i + 0] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NT; ++i) v[i] = base[offm[0] + kofs[i]];
-    }
-  }
-
-  // write the staged tile (loaded from k0) into its LDS image; FULL skips the bounds masks
-  template <bool FULL>
-  __device__ __forceinline__ void store(float* __restrict__ s, int k0, int K, int tid) const {
-    if (MODE == 1) {
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int kr = tid / VPR + RPP * i;
-        const bool in = FULL || (okm[0] && (k0 + kr) < K);
-        *reinterpret_cast<float4*>(s + kr * ROWS + (tid % VPR) * 4) =
-            make_float4(in ? v[4 * i] : 0.f, in ? v[4 * i + 1] : 0.f, in ? v[4 * i + 2] : 0.f,
-                        in ? v[4 * i + 3] : 0.f);
-      }
-    } else if (MODE == 2) {
-      const bool kin = (k0 + (tid % (BK / 4)) * 4) < K;
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        const bool in = FULL || (okm[i] && kin);
-        float* d = s + ((tid + i * 256) / (BK / 4)) * LDK + (tid % (BK / 4)) * 4;
-        d[0] = in ? v[4 * i] : 0.f; d[1] = in ? v[4 * i + 1] : 0.f;
-        d[2] = in ? v[4 * i + 2] : 0.f; d[3] = in ? v[4 * i + 3] : 0.f;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int kr = tid / ROWS + KPP * i;
-        const bool in = FULL || (okm[0] && (k0 + kr) < K);
-        s[kr * ROWS + (tid % ROWS)] = in ? v[i] : 0.f;
-      }
-    }
-  }
-
-  // LDS index of element (row, k) of the tile image
-  static __device__ __forceinline__ int idx(int row, int k) {
-    return MODE == 2 ? row * LDK + k : k * ROWS + row;
-  }
-};
-
-template <int MA, int MB, int BK, int TN, bool FULL>
-__device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLoader<MB, BK, TN>& lb,
-                                              const float* __restrict__ A, const float* __restrict__ B,
-                                              const int32_t* __restrict__ okA, const int32_t* __restrict__ okB,
-                                              int K, float* sA, float* sB, f32x16 (&acc)[2][TN / 64], int tid,
-                                              unsigned long long* dbg1) {
-  using LA = TileLoader<MA, BK, BM>;
-  using LB = TileLoader<MB, BK, TN>;
-  constexpr int SZA = LA::kSize, SZB = LB::kSize;
-  constexpr int NJ = TN / 64;  // 32-wide column blocks per wave
-  const int lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * 64, wn = (w & 1) * (TN / 2);
-  const int l31 = lane & 31, h = lane >> 5;
-
-  const int nkt = (K + BK - 1) / BK;
-  la.tab(okA, 0, tid);
-  lb.tab(okB, 0, tid);
-  la.load(A);
-  lb.load(B);
-  la.tab(okA, BK, tid);
-  lb.tab(okB, BK, tid);
-  la.template store<FULL>(sA, 0, K, tid);
-  lb.template store<FULL>(sB, 0, K, tid);
-  __syncthreads();
-#ifdef CTN_STAMPS
-  if (dbg1 && tid == 0) *dbg1 = __builtin_amdgcn_s_memtime();
-#endif
-
-  // per-lane LDS fragment bases (element indices)
-  const int fa0 = LA::idx(wm + l31, h), fa1 = LA::idx(wm + 32 + l31, h);
-  int fbx[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) fbx[j] = LB::idx(wn + j * 32 + l31, h);
-  constexpr int stepA = MA == 2 ? 2 : 2 * BM;  // advance of the fragment index per k-step (k += 2)
-  constexpr int stepB = MB == 2 ? 2 : 2 * TN;
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nkt;
-    if (more) {
-      la.load(A);
-      lb.load(B);
-      la.tab(okA, (kt + 2) * BK, tid);
-      lb.tab(okB, (kt + 2) * BK, tid);
-    }
-    __builtin_amdgcn_sched_barrier(0);  // global loads stay in front of the MFMA phase
-    const float* cA = sA + cur * SZA;
-    const float* cB = sB + cur * SZB;
-    float fa[2][2], fb[2][NJ];
-    fa[0][0] = cA[fa0]; fa[0][1] = cA[fa1];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) fb[0][j] = cB[fbx[j]];
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const int c = kk & 1, nx = c ^ 1;
-      if (kk + 1 < BK / 2) {
-        fa[nx][0] = cA[fa0 + (kk + 1) * stepA]; fa[nx][1] = cA[fa1 + (kk + 1) * stepA];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) fb[nx][j] = cB[fbx[j] + (kk + 1) * stepB];
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
-      // pin the interleave: the LDS reads of step kk+1 issue ahead of the MFMAs of step kk
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);  // the staged tile is consumed only after the MFMA phase
-    if (more) {
-      la.template store<FULL>(sA + (cur ^ 1) * SZA, (kt + 1) * BK, K, tid);
-      lb.template store<FULL>(sB + (cur ^ 1) * SZB, (kt + 1) * BK, K, tid);
-    }
-    __syncthreads();
-  }
-}
-
-// second launch-bound argument = waves per SIMD the register allocator must leave room for:
-// BK = 16 is sized for 3 workgroups per CU (<= 168 registers), BK = 32 for 2
-template <int MA, int MB, int BK, int TN>
-__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a) {
-  using LA = TileLoader<MA, BK, BM>;
-  using LB = TileLoader<MB, BK, TN>;
-  constexpr int SZA = LA::kSize, SZB = LB::kSize;
-  constexpr int NJ = TN / 64;
-  // one LDS object: [A buf0][A buf1][B buf0][B buf1][omC 128][onC TN][red 4 doubles]
-  __shared__ __attribute__((aligned(16))) float smem[2 * SZA + 2 * SZB + BM + TN + 8];
-  float* sA = smem;
-  float* sB = smem + 2 * SZA;
-  int* s_omC = reinterpret_cast<int*>(smem + 2 * SZA + 2 * SZB);
-  int* s_onC = s_omC + BM;
-  double* red = reinterpret_cast<double*>(s_onC + TN);
-
-  const int tid = threadIdx.x;
-  // XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs, so give each
-  // XCD a contiguous range of tiles (one replica's tiles share that XCD's L2).
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
-  const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  const int r = pid / a.blocks_per_replica;
-  const int t = pid - r * a.blocks_per_replica;
-  const int tiles_mn = a.tiles_m * a.tiles_n;
-  const int b = t / tiles_mn;
-  const int tt = t - b * tiles_mn;
-  const int m0 = (tt / a.tiles_n) * BM;
-  const int n0 = (tt % a.tiles_n) * TN;
-
-#ifdef CTN_STAMPS
-  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 0] = __builtin_amdgcn_s_memtime();
-#endif
-  const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
-
-  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
-  const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
-  const float* __restrict__ B = (const float*)tp[a.idB] + a.obB[b];
-  float* __restrict__ C = (float*)tp[a.idC] + a.obC[b];
-
-  if (tid < BM) s_omC[tid] = a.omC[m0 + tid];
-  else if (tid - BM < TN) s_onC[tid - BM] = a.onC[n0 + tid - BM];
-
-  LA la;
-  LB lb;
-  la.init(a.omA, m0, a.M, tid);
-  lb.init(a.onB, n0, a.N, tid);
-
-  const int lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * 64, wn = (w & 1) * (TN / 2);
-  const int l31 = lane & 31, h = lane >> 5;
-
-  f32x16 acc[2][NJ];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-#ifdef CTN_STAMPS
-  unsigned long long* stamp1 = a.dbg ? a.dbg + (size_t)pid * 4 + 1 : nullptr;
-#else
-  unsigned long long* stamp1 = nullptr;
-#endif
-  // FULL: the tile lies completely inside M x N and K is a multiple of BK -> no masking
-  const bool full = (m0 + BM <= a.M) && (n0 + TN <= a.N) && (a.K % BK == 0);
-  if (full) mfma_mainloop<MA, MB, BK, TN, true>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
-  else mfma_mainloop<MA, MB, BK, TN, false>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
-#ifdef CTN_STAMPS
-  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 2] = __builtin_amdgcn_s_memtime();
-#endif
-
-  // epilogue: lazy rescale, store through the C offset tables, abs-sum partial
-  const float iA = 1.0f / scA, iB = 1.0f / scB;
-  float asum = 0.f;
-  {
-    // Each WAVE stages its own 64 x TN/2 accumulator block through its quarter of the (now idle)
-    // operand buffers, 32 rows at a time, and stores whole 16-byte row segments (4-8 rows of
-    // 128-256 contiguous bytes per store instruction).  No workgroup barrier is involved: LDS
-    // operations of one wave execute in order, so the write -> read hand-off is wave-local.
-    constexpr int WT = TN / 2;                       // columns owned by a wave
-    constexpr int LDSW = ((2 * SZA + 2 * SZB) / 4) & ~3;  // floats of LDS per wave (16-byte aligned)
-    static_assert(LDSW >= 32 * WT, "per-wave staging area too small");
-    constexpr int VW = WT / 4;                       // 16-byte vectors per row
-    constexpr int RPI = 64 / VW;                     // rows covered by one wave-wide vector access
-    float* wC = smem + w * LDSW;                     // [32][WT]
-    const int c4 = (lane % VW) * 4;
-    const int gcol = wn + c4;
-    const bool cin = n0 + gcol < a.N;  // N % 4 == 0 whenever c_vec, otherwise checked per element
-    const int offn = s_onC[gcol];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          wC[((e & 3) + 8 * (e >> 2) + 4 * h) * WT + j * 32 + l31] = (acc[i][j][e] * iA) * iB;
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int it = 0; it < 32 / RPI; ++it) {
-        const int lrow = it * RPI + lane / VW;
-        const int row = wm + i * 32 + lrow;
-        const float4 v = *reinterpret_cast<const float4*>(wC + lrow * WT + c4);
-        if (m0 + row < a.M && cin) {
-          float* dst = C + s_omC[row];
-          if (a.c_vec) {
-            *reinterpret_cast<float4*>(dst + offn) = v;
-            asum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
-          } else {
-            const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (n0 + gcol + q < a.N) {
-                dst[s_onC[gcol + q]] = vv[q];
-                asum += fabsf(vv[q]);
-              }
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  const double tot = block_sum((double)asum, red);
-  if (tid == 0) a.partC[(size_t)r * a.partC_stride + t] = tot;
-#ifdef CTN_STAMPS
-  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 3] = __builtin_amdgcn_s_memtime();
-#endif
-}
-
-// ---------------------------------------------------------------------------
-// K-mfma-f64: 64x64 workgroup tile, 4 waves (2x2), each wave 32x32 = 2x2
-// v_mfma_f64_16x16x4_f64 accumulators, BK = 16, table-driven gather loads coalesced along the
-// free index, LDS image [k][80] (row stride = 640 B = 32 banks mod 64: the two k rows a 32-lane
-// group reads fall on disjoint bank halves).  f64 C/D map (NOT the f32 one): col = lane & 15,
-// row = (lane >> 4) + 4 * reg.
-// ---------------------------------------------------------------------------
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256) void k_mfma_f64(StepArgs a) {
-  constexpr int T64 = kTile64, BK = 16, LD = 80, SZ = BK * LD;
-  __shared__ __attribute__((aligned(16))) double smem[4 * SZ + 8];
-  __shared__ int s_omC[T64], s_onC[T64];
-  double* sA = smem;
-  double* sB = smem + 2 * SZ;
-  double* red = smem + 4 * SZ;
-
-  const int tid = threadIdx.x;
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
-  const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  const int r = pid / a.blocks_per_replica;
-  const int t = pid - r * a.blocks_per_replica;
-  const int tiles_mn = a.tiles_m * a.tiles_n;
-  const int b = t / tiles_mn;
-  const int tt = t - b * tiles_mn;
-  const int m0 = (tt / a.tiles_n) * T64;
-  const int n0 = (tt % a.tiles_n) * T64;
-
-  const double scA = producer_scale<double>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const double scB = producer_scale<double>(a.partB, a.PB, a.numelB, a.min_norm, r);
-  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
-  const double* __restrict__ A = (const double*)tp[a.idA] + a.obA[b];
-  const double* __restrict__ B = (const double*)tp[a.idB] + a.obB[b];
-  double* __restrict__ C = (double*)tp[a.idC] + a.obC[b];
-
-  if (tid < T64) s_omC[tid] = a.omC[m0 + tid];
-  else if (tid < 2 * T64) s_onC[tid - T64] = a.onC[n0 + tid - T64];
-
-  // staging: element (free = tid & 63, k = (tid >> 6) + 4 i), i < 4, for both operands
-  const int fr = tid & 63, kr = tid >> 6;
-  const int offa = a.omA[m0 + fr], offb = a.onB[n0 + fr];
-  const bool ina = m0 + fr < a.M, inb = n0 + fr < a.N;
-  double va[4], vb[4];
-  int ka[4], kb[4];
-  auto tab = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { ka[i] = a.okA[k0 + kr + 4 * i]; kb[i] = a.okB[k0 + kr + 4 * i]; }
-  };
-  auto load = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { va[i] = A[offa + ka[i]]; vb[i] = B[offb + kb[i]]; }
-  };
-  auto store = [&](double* dA, double* dB, int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool kin = k0 + kr + 4 * i < a.K;
-      dA[(kr + 4 * i) * LD + fr] = (ina && kin) ? va[i] : 0.0;
-      dB[(kr + 4 * i) * LD + fr] = (inb && kin) ? vb[i] : 0.0;
-    }
-  };
-
-  const int lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
-  const int l15 = lane & 15, q = lane >> 4;
-  f64x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
-
-  const int nkt = (a.K + BK - 1) / BK;
-  tab(0);
-  load();
-  tab(BK);
-  store(sA, sB, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nkt;
-    if (more) {
-      load();
-      tab((kt + 2) * BK);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const double* cA = sA + cur * SZ;
-    const double* cB = sB + cur * SZ;
-#pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      const int k = kk * 4 + q;
-      const double a0 = cA[k * LD + wm + l15], a1 = cA[k * LD + wm + 16 + l15];
-      const double b0 = cB[k * LD + wn + l15], b1 = cB[k * LD + wn + 16 + l15];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) store(sA + (cur ^ 1) * SZ, sB + (cur ^ 1) * SZ, (kt + 1) * BK);
-    __syncthreads();
-  }
-
-  // epilogue: operands' rescale factors divide the accumulator (division, as in the reference)
-  double asum = 0.0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = wn + j * 16 + l15;
-      const bool cin = n0 + col < a.N;
-      const int offn = s_onC[col];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = wm + i * 16 + q + 4 * e;
-        if (cin && m0 + row < a.M) {
-          const double v = (acc[i][j][e] / scA) / scB;
-          C[s_omC[row] + offn] = v;
-          asum += fabs(v);
-        }
-      }
-    }
-  const double tot = block_sum(asum, red);
-  if (tid == 0) a.partC[(size_t)r * a.partC_stride + t] = tot;
-}
-
-// ---------------------------------------------------------------------------
-// K-chain: persistent small-tensor DAG walker.  One workgroup per replica executes EVERY step of
-// the plan in order (reference loop einsum.py:341-391) - no per-step launch, rescale factors of
-// all produced tensors kept in LDS.  Same arithmetic as k_element (operands divided by their
-// producer's rescale on load), so results are bit-identical to the per-step path.
-// ---------------------------------------------------------------------------
-struct ChainStep {
-  const int32_t *obA, *obB, *obC, *omA, *omC, *onB, *onC, *okA, *okB;
-  double numelC;
-  int32_t Bt, M, N, K;
-  int32_t idA, idB, idC;
-  int32_t prodA, prodB;  // producing step of each operand, -1 for inputs
-};
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_chain(const ChainStep* __restrict__ steps, int n_steps,
-                                               void* const* ptrs, int n_tensors, double* partials,
-                                               int R, double min_norm, int stabilize) {
-  __shared__ double red[4];
-  __shared__ T sc[kChainMaxSteps];
-  const int r = blockIdx.x;
-  void* const* tp = ptrs + (size_t)r * n_tensors;
-  for (int s = 0; s < n_steps; ++s) {
-    const ChainStep d = steps[s];
-    const T sA = d.prodA >= 0 ? sc[d.prodA] : (T)1;
-    const T sB = d.prodB >= 0 ? sc[d.prodB] : (T)1;
-    const T* __restrict__ A = (const T*)tp[d.idA];
-    const T* __restrict__ B = (const T*)tp[d.idB];
-    T* __restrict__ C = (T*)tp[d.idC];
-    const int total = d.Bt * d.M * d.N;
-    double absv = 0;
-    for (int o = threadIdx.x; o < total; o += 256) {
-      const int n = o % d.N;
-      const int q = o / d.N;
-      const int m = q % d.M;
-      const int b = q / d.M;
-      const T* pa = A + d.obA[b] + d.omA[m];
-      const T* pb = B + d.obB[b] + d.onB[n];
-      T acc = 0;
-      for (int k = 0; k < d.K; ++k) acc = fma(pa[d.okA[k]] / sA, pb[d.okB[k]] / sB, acc);
-      C[d.obC[b] + d.omC[m] + d.onC[n]] = acc;
-      absv += (double)fabs(acc);
-    }
-    // the barriers inside block_sum also order this step's stores before the next step's loads
-    const double tot = block_sum(absv, red);
-    if (threadIdx.x == 0) {
-      partials[((size_t)s * R + r) * kMaxPartials] = tot;
-      const T norm = (T)tot;
-      sc[s] = (stabilize && norm > (T)min_norm) ? norm / (T)d.numelC : (T)1;
-    }
-    __syncthreads();
-  }
-}
 
 // ---------------------------------------------------------------------------
 // executor

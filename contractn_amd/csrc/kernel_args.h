@@ -1,0 +1,109 @@
+// kernel_args.h - kernel argument structs and device helpers shared by every kernel
+// Part of the gfx950 contraction engine (see engine.hip for the overview).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "plan.h"
+
+namespace ctn {
+
+// ---------------------------------------------------------------------------
+// kernel arguments
+// ---------------------------------------------------------------------------
+// n / d for 0 <= n < 2^31 by multiply-shift (host-precomputed): exact, ~5 instructions instead of
+// the ~40 (32-bit) / ~100 (64-bit) of a hardware-less integer division.
+struct FastDiv {
+  uint64_t M;
+  uint32_t d;
+  int32_t k;
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return (uint32_t)(((uint64_t)n * M) >> k); }
+};
+static FastDiv make_fastdiv(int64_t d64) {
+  FastDiv f;
+  const uint32_t d = (uint32_t)std::max<int64_t>(d64, 1);
+  int lg = 0;
+  while ((1ull << lg) < d) ++lg;
+  f.d = d;
+  f.k = 31 + lg;
+  f.M = ((1ull << f.k) / d) + 1;   // n * M < 2^31 * 2^(32) fits in 64 bits; exact for n < 2^31
+  if (d == 1) { f.M = 1; f.k = 0; }
+  return f;
+}
+
+struct StepArgs {
+  const int32_t *obA, *obB, *obC, *omA, *omC, *onB, *onC, *okA, *okB;
+  void* const* ptrs;    // [R][n_tensors] base pointer of every tensor of every replica
+  const double* partA;  // [R][64] abs-sum partials of A's producer step, nullptr for inputs
+  const double* partB;
+  double* partC;        // [R][partC_stride] where this step's partials go
+  double numelA, numelB;
+  double min_norm;
+  int32_t Bt, M, N, K;
+  int32_t idA, idB, idC, n_tensors;
+  int32_t PA, PB;
+  int32_t partC_stride;
+  int32_t tiles_m, tiles_n;
+  int32_t blocks_per_replica;
+  int32_t R;
+  int32_t c_vec;  // float4 stores of C allowed
+  // streaming kernels: output index = (hi, lo, n); n along C's unit-stride label
+  const int32_t *ohA, *ohB, *ohC, *olA, *olB, *olC;
+  int32_t H, L, Nv, sAn, sBn;
+  FastDiv dNq, dL, dNv;  // divisors: vectors per row, lo extent, n extent
+  unsigned long long* dbg;  // CTN_STAMPS builds only: 4 cycle stamps per MFMA tile (else unused, null)
+};
+
+struct FinalArgs {
+  void* const* ptrs;
+  const double* partials;   // [n_steps][R][64]
+  const int32_t* stepP;     // [n_steps] partial count of each step
+  const double* stepNumel;  // [n_steps] numel of each step's output
+  double* log_scale;        // [R]
+  double* rescales;         // [R][n_steps]
+  double min_norm;
+  int64_t out_numel;
+  int32_t n_steps, R, id_out, n_tensors, stabilize;
+};
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+// Rescale factor of a tensor from its producer's partial sums (reference
+// einsum.py:97-102: norm = sum|T|, rescale = norm / numel, applied iff
+// norm > min_norm).  All 64 lanes of the calling wave must be active.
+template <typename T>
+__device__ __forceinline__ T producer_scale(const double* part, int P, double numel, double min_norm,
+                                            int r, bool* cond_out = nullptr) {
+  if (part == nullptr) {
+    if (cond_out) *cond_out = false;
+    return (T)1;
+  }
+  const int lane = threadIdx.x & 63;
+  double v = lane < P ? part[(size_t)r * kMaxPartials + lane] : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const T norm = (T)v;
+  const bool cond = norm > (T)min_norm;
+  if (cond_out) *cond_out = cond;
+  return cond ? norm / (T)numel : (T)1;
+}
+
+// Sum over the workgroup in a fixed order; result valid in every thread.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  double t = 0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+
+}  // namespace ctn

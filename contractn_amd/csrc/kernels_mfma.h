@@ -1,0 +1,474 @@
+// kernels_mfma.h - MFMA GEMM kernels (fp32 v_mfma_f32_32x32x2_f32, fp64 v_mfma_f64_16x16x4_f64) with table-driven gather loads
+// Part of the gfx950 contraction engine (see engine.hip for the overview).
+#pragma once
+#include "kernel_args.h"
+
+namespace ctn {
+
+// ---------------------------------------------------------------------------
+// K-mfma-f32: 128 x TN workgroup tile (TN = 128 or 64), 4 waves (2x2), each wave
+// 64 x TN/2 = 2 x TN/64 v_mfma_f32_32x32x2_f32 accumulators, register-staged
+// double-buffered LDS, one barrier per k-tile.  TN = 64 serves skinny products
+// (boundary absorptions of 2D grids: N = 64) where a 128-wide tile would be half masked.
+//
+// MODE (per operand): 0 scalar gather, 1 float4 along the free index (LDS image
+// [k][rows]), 2 float4 along k (LDS image [rows][BK+1], odd row length => conflict-free
+// ds_read_b32 for the MFMA fragment: lane l reads row l&31, k = 2*kk + (l>>5)).
+//
+// Latency structure: the k-offset table entries of tile t+2 are requested while
+// tile t+1's data loads are in flight and tile t is being multiplied, so no
+// load ever waits on a table lookup; global loads are unconditional (padded
+// tables keep every address in bounds) and masked when written to LDS; LDS fragment
+// reads run one k-step ahead of the MFMAs that consume them.
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = kTileM;
+
+// Stages one ROWS x BK operand tile per k-step: global -> registers -> LDS.
+template <int MODE, int BK, int ROWS>
+struct TileLoader {
+  static constexpr int NV = ROWS * BK / 256;               // floats staged per thread
+  static constexpr int VPR = ROWS / 4;                     // mode 1: float4 per k-row
+  static constexpr int RPP = 256 / VPR;                    // mode 1: k-rows covered per pass
+  static constexpr int KPP = 256 / ROWS;                   // mode 0: k-rows covered per pass
+  static constexpr int NT = MODE == 1 ? BK / RPP : (MODE == 2 ? 1 : NV);  // table entries per tile
+  static constexpr int NM = MODE == 2 ? NV / 4 : 1;        // hoisted free-index offsets
+  static constexpr int LDK = BK + 1;
+  static constexpr int kSize = MODE == 2 ? ROWS * LDK : BK * ROWS;
+  static_assert(NV >= 4 && NT >= 1 && NM >= 1, "tile too small for 256 threads");
+
+  float v[NV];
+  int kofs[NT];   // k-offset table entries of the NEXT tile to load
+  int offm[NM];
+  bool okm[NM];
+
+  __device__ __forceinline__ void init(const int32_t* __restrict__ om, int m0, int M, int tid) {
+    if (MODE == 1) {
+      const int gm = m0 + (tid % VPR) * 4;
+      offm[0] = om[gm];
+      okm[0] = gm < M;
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const int gm = m0 + ((tid + i * 256) / (BK / 4));
+        offm[i] = om[gm];
+        okm[i] = gm < M;
+      }
+    } else {
+      const int gm = m0 + (tid % ROWS);
+      offm[0] = om[gm];
+      okm[0] = gm < M;
+    }
+  }
+
+  // request the table entries this thread needs for the tile starting at k0 (table is padded)
+  __device__ __forceinline__ void tab(const int32_t* __restrict__ ok, int k0, int tid) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + tid / VPR + RPP * i];
+    } else if (MODE == 2) {
+      kofs[0] = ok[k0 + (tid % (BK / 4)) * 4];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + tid / ROWS + KPP * i];
+    }
+  }
+
+  // issue the global loads of the tile using the entries fetched by the previous tab().
+  // Unconditional: padded tables keep every address inside the tensor; out-of-range rows and
+  // k are zeroed later, in store(), so nothing here waits on the data.
+  __device__ __forceinline__ void load(const float* __restrict__ base) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const float4 x = *reinterpret_cast<const float4*>(base + offm[0] + kofs[i]);
+        v[4 * i + 0] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+      }
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const float4 x = *reinterpret_cast<const float4*>(base + offm[i] + kofs[0]);
+        v[4 * i + 0] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) v[i] = base[offm[0] + kofs[i]];
+    }
+  }
+
+  // write the staged tile (loaded from k0) into its LDS image; FULL skips the bounds masks
+  template <bool FULL>
+  __device__ __forceinline__ void store(float* __restrict__ s, int k0, int K, int tid) const {
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int kr = tid / VPR + RPP * i;
+        const bool in = FULL || (okm[0] && (k0 + kr) < K);
+        *reinterpret_cast<float4*>(s + kr * ROWS + (tid % VPR) * 4) =
+            make_float4(in ? v[4 * i] : 0.f, in ? v[4 * i + 1] : 0.f, in ? v[4 * i + 2] : 0.f,
+                        in ? v[4 * i + 3] : 0.f);
+      }
+    } else if (MODE == 2) {
+      const bool kin = (k0 + (tid % (BK / 4)) * 4) < K;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const bool in = FULL || (okm[i] && kin);
+        float* d = s + ((tid + i * 256) / (BK / 4)) * LDK + (tid % (BK / 4)) * 4;
+        d[0] = in ? v[4 * i] : 0.f; d[1] = in ? v[4 * i + 1] : 0.f;
+        d[2] = in ? v[4 * i + 2] : 0.f; d[3] = in ? v[4 * i + 3] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int kr = tid / ROWS + KPP * i;
+        const bool in = FULL || (okm[0] && (k0 + kr) < K);
+        s[kr * ROWS + (tid % ROWS)] = in ? v[i] : 0.f;
+      }
+    }
+  }
+
+  // LDS index of element (row, k) of the tile image
+  static __device__ __forceinline__ int idx(int row, int k) {
+    return MODE == 2 ? row * LDK + k : k * ROWS + row;
+  }
+};
+
+template <int MA, int MB, int BK, int TN, bool FULL>
+__device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLoader<MB, BK, TN>& lb,
+                                              const float* __restrict__ A, const float* __restrict__ B,
+                                              const int32_t* __restrict__ okA, const int32_t* __restrict__ okB,
+                                              int K, float* sA, float* sB, f32x16 (&acc)[2][TN / 64], int tid,
+                                              unsigned long long* dbg1) {
+  using LA = TileLoader<MA, BK, BM>;
+  using LB = TileLoader<MB, BK, TN>;
+  constexpr int SZA = LA::kSize, SZB = LB::kSize;
+  constexpr int NJ = TN / 64;  // 32-wide column blocks per wave
+  const int lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * (TN / 2);
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int nkt = (K + BK - 1) / BK;
+  la.tab(okA, 0, tid);
+  lb.tab(okB, 0, tid);
+  la.load(A);
+  lb.load(B);
+  la.tab(okA, BK, tid);
+  lb.tab(okB, BK, tid);
+  la.template store<FULL>(sA, 0, K, tid);
+  lb.template store<FULL>(sB, 0, K, tid);
+  __syncthreads();
+#ifdef CTN_STAMPS
+  if (dbg1 && tid == 0) *dbg1 = __builtin_amdgcn_s_memtime();
+#endif
+
+  // per-lane LDS fragment bases (element indices)
+  const int fa0 = LA::idx(wm + l31, h), fa1 = LA::idx(wm + 32 + l31, h);
+  int fbx[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) fbx[j] = LB::idx(wn + j * 32 + l31, h);
+  constexpr int stepA = MA == 2 ? 2 : 2 * BM;  // advance of the fragment index per k-step (k += 2)
+  constexpr int stepB = MB == 2 ? 2 : 2 * TN;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      la.load(A);
+      lb.load(B);
+      la.tab(okA, (kt + 2) * BK, tid);
+      lb.tab(okB, (kt + 2) * BK, tid);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // global loads stay in front of the MFMA phase
+    const float* cA = sA + cur * SZA;
+    const float* cB = sB + cur * SZB;
+    float fa[2][2], fb[2][NJ];
+    fa[0][0] = cA[fa0]; fa[0][1] = cA[fa1];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) fb[0][j] = cB[fbx[j]];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int c = kk & 1, nx = c ^ 1;
+      if (kk + 1 < BK / 2) {
+        fa[nx][0] = cA[fa0 + (kk + 1) * stepA]; fa[nx][1] = cA[fa1 + (kk + 1) * stepA];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[nx][j] = cB[fbx[j] + (kk + 1) * stepB];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
+      // pin the interleave: the LDS reads of step kk+1 issue ahead of the MFMAs of step kk
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the staged tile is consumed only after the MFMA phase
+    if (more) {
+      la.template store<FULL>(sA + (cur ^ 1) * SZA, (kt + 1) * BK, K, tid);
+      lb.template store<FULL>(sB + (cur ^ 1) * SZB, (kt + 1) * BK, K, tid);
+    }
+    __syncthreads();
+  }
+}
+
+// second launch-bound argument = waves per SIMD the register allocator must leave room for:
+// BK = 16 is sized for 3 workgroups per CU (<= 168 registers), BK = 32 for 2
+template <int MA, int MB, int BK, int TN>
+__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a) {
+  using LA = TileLoader<MA, BK, BM>;
+  using LB = TileLoader<MB, BK, TN>;
+  constexpr int SZA = LA::kSize, SZB = LB::kSize;
+  constexpr int NJ = TN / 64;
+  // one LDS object: [A buf0][A buf1][B buf0][B buf1][omC 128][onC TN][red 4 doubles]
+  __shared__ __attribute__((aligned(16))) float smem[2 * SZA + 2 * SZB + BM + TN + 8];
+  float* sA = smem;
+  float* sB = smem + 2 * SZA;
+  int* s_omC = reinterpret_cast<int*>(smem + 2 * SZA + 2 * SZB);
+  int* s_onC = s_omC + BM;
+  double* red = reinterpret_cast<double*>(s_onC + TN);
+
+  const int tid = threadIdx.x;
+  // XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs, so give each
+  // XCD a contiguous range of tiles (one replica's tiles share that XCD's L2).
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+  const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int r = pid / a.blocks_per_replica;
+  const int t = pid - r * a.blocks_per_replica;
+  const int tiles_mn = a.tiles_m * a.tiles_n;
+  const int b = t / tiles_mn;
+  const int tt = t - b * tiles_mn;
+  const int m0 = (tt / a.tiles_n) * BM;
+  const int n0 = (tt % a.tiles_n) * TN;
+
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 0] = __builtin_amdgcn_s_memtime();
+#endif
+  const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
+
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
+  const float* __restrict__ B = (const float*)tp[a.idB] + a.obB[b];
+  float* __restrict__ C = (float*)tp[a.idC] + a.obC[b];
+
+  if (tid < BM) s_omC[tid] = a.omC[m0 + tid];
+  else if (tid - BM < TN) s_onC[tid - BM] = a.onC[n0 + tid - BM];
+
+  LA la;
+  LB lb;
+  la.init(a.omA, m0, a.M, tid);
+  lb.init(a.onB, n0, a.N, tid);
+
+  const int lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * (TN / 2);
+  const int l31 = lane & 31, h = lane >> 5;
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#ifdef CTN_STAMPS
+  unsigned long long* stamp1 = a.dbg ? a.dbg + (size_t)pid * 4 + 1 : nullptr;
+#else
+  unsigned long long* stamp1 = nullptr;
+#endif
+  // FULL: the tile lies completely inside M x N and K is a multiple of BK -> no masking
+  const bool full = (m0 + BM <= a.M) && (n0 + TN <= a.N) && (a.K % BK == 0);
+  if (full) mfma_mainloop<MA, MB, BK, TN, true>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
+  else mfma_mainloop<MA, MB, BK, TN, false>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 2] = __builtin_amdgcn_s_memtime();
+#endif
+
+  // epilogue: lazy rescale, store through the C offset tables, abs-sum partial
+  const float iA = 1.0f / scA, iB = 1.0f / scB;
+  float asum = 0.f;
+  {
+    // Each WAVE stages its own 64 x TN/2 accumulator block through its quarter of the (now idle)
+    // operand buffers, 32 rows at a time, and stores whole 16-byte row segments (4-8 rows of
+    // 128-256 contiguous bytes per store instruction).  No workgroup barrier is involved: LDS
+    // operations of one wave execute in order, so the write -> read hand-off is wave-local.
+    constexpr int WT = TN / 2;                       // columns owned by a wave
+    constexpr int LDSW = ((2 * SZA + 2 * SZB) / 4) & ~3;  // floats of LDS per wave (16-byte aligned)
+    static_assert(LDSW >= 32 * WT, "per-wave staging area too small");
+    constexpr int VW = WT / 4;                       // 16-byte vectors per row
+    constexpr int RPI = 64 / VW;                     // rows covered by one wave-wide vector access
+    float* wC = smem + w * LDSW;                     // [32][WT]
+    const int c4 = (lane % VW) * 4;
+    const int gcol = wn + c4;
+    const bool cin = n0 + gcol < a.N;  // N % 4 == 0 whenever c_vec, otherwise checked per element
+    const int offn = s_onC[gcol];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          wC[((e & 3) + 8 * (e >> 2) + 4 * h) * WT + j * 32 + l31] = (acc[i][j][e] * iA) * iB;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int lrow = it * RPI + lane / VW;
+        const int row = wm + i * 32 + lrow;
+        const float4 v = *reinterpret_cast<const float4*>(wC + lrow * WT + c4);
+        if (m0 + row < a.M && cin) {
+          float* dst = C + s_omC[row];
+          if (a.c_vec) {
+            *reinterpret_cast<float4*>(dst + offn) = v;
+            asum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+          } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (n0 + gcol + q < a.N) {
+                dst[s_onC[gcol + q]] = vv[q];
+                asum += fabsf(vv[q]);
+              }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  const double tot = block_sum((double)asum, red);
+  if (tid == 0) a.partC[(size_t)r * a.partC_stride + t] = tot;
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 3] = __builtin_amdgcn_s_memtime();
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// K-mfma-f64: 64x64 workgroup tile, 4 waves (2x2), each wave 32x32 = 2x2
+// v_mfma_f64_16x16x4_f64 accumulators, BK = 16, table-driven gather loads coalesced along the
+// free index, LDS image [k][80] (row stride = 640 B = 32 banks mod 64: the two k rows a 32-lane
+// group reads fall on disjoint bank halves).  f64 C/D map (NOT the f32 one): col = lane & 15,
+// row = (lane >> 4) + 4 * reg.
+// ---------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_mfma_f64(StepArgs a) {
+  constexpr int T64 = kTile64, BK = 16, LD = 80, SZ = BK * LD;
+  __shared__ __attribute__((aligned(16))) double smem[4 * SZ + 8];
+  __shared__ int s_omC[T64], s_onC[T64];
+  double* sA = smem;
+  double* sB = smem + 2 * SZ;
+  double* red = smem + 4 * SZ;
+
+  const int tid = threadIdx.x;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+  const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int r = pid / a.blocks_per_replica;
+  const int t = pid - r * a.blocks_per_replica;
+  const int tiles_mn = a.tiles_m * a.tiles_n;
+  const int b = t / tiles_mn;
+  const int tt = t - b * tiles_mn;
+  const int m0 = (tt / a.tiles_n) * T64;
+  const int n0 = (tt % a.tiles_n) * T64;
+
+  const double scA = producer_scale<double>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const double scB = producer_scale<double>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const double* __restrict__ A = (const double*)tp[a.idA] + a.obA[b];
+  const double* __restrict__ B = (const double*)tp[a.idB] + a.obB[b];
+  double* __restrict__ C = (double*)tp[a.idC] + a.obC[b];
+
+  if (tid < T64) s_omC[tid] = a.omC[m0 + tid];
+  else if (tid < 2 * T64) s_onC[tid - T64] = a.onC[n0 + tid - T64];
+
+  // staging: element (free = tid & 63, k = (tid >> 6) + 4 i), i < 4, for both operands
+  const int fr = tid & 63, kr = tid >> 6;
+  const int offa = a.omA[m0 + fr], offb = a.onB[n0 + fr];
+  const bool ina = m0 + fr < a.M, inb = n0 + fr < a.N;
+  double va[4], vb[4];
+  int ka[4], kb[4];
+  auto tab = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ka[i] = a.okA[k0 + kr + 4 * i]; kb[i] = a.okB[k0 + kr + 4 * i]; }
+  };
+  auto load = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { va[i] = A[offa + ka[i]]; vb[i] = B[offb + kb[i]]; }
+  };
+  auto store = [&](double* dA, double* dB, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool kin = k0 + kr + 4 * i < a.K;
+      dA[(kr + 4 * i) * LD + fr] = (ina && kin) ? va[i] : 0.0;
+      dB[(kr + 4 * i) * LD + fr] = (inb && kin) ? vb[i] : 0.0;
+    }
+  };
+
+  const int lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+  const int l15 = lane & 15, q = lane >> 4;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+
+  const int nkt = (a.K + BK - 1) / BK;
+  tab(0);
+  load();
+  tab(BK);
+  store(sA, sB, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      load();
+      tab((kt + 2) * BK);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const double* cA = sA + cur * SZ;
+    const double* cB = sB + cur * SZ;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int k = kk * 4 + q;
+      const double a0 = cA[k * LD + wm + l15], a1 = cA[k * LD + wm + 16 + l15];
+      const double b0 = cB[k * LD + wn + l15], b1 = cB[k * LD + wn + 16 + l15];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) store(sA + (cur ^ 1) * SZ, sB + (cur ^ 1) * SZ, (kt + 1) * BK);
+    __syncthreads();
+  }
+
+  // epilogue: operands' rescale factors divide the accumulator (division, as in the reference)
+  double asum = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wn + j * 16 + l15;
+      const bool cin = n0 + col < a.N;
+      const int offn = s_onC[col];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = wm + i * 16 + q + 4 * e;
+        if (cin && m0 + row < a.M) {
+          const double v = (acc[i][j][e] / scA) / scB;
+          C[s_omC[row] + offn] = v;
+          asum += fabs(v);
+        }
+      }
+    }
+  const double tot = block_sum(asum, red);
+  if (tid == 0) a.partC[(size_t)r * a.partC_stride + t] = tot;
+}
+
+
+}  // namespace ctn

@@ -1,0 +1,301 @@
+// kernels_stream.h - HBM-bound kernels: streaming hyperedge gather-multiply, row-dot, dot, collapse, finishing passes, chain walker
+// Part of the gfx950 contraction engine (see engine.hip for the overview).
+#pragma once
+#include "kernel_args.h"
+
+namespace ctn {
+
+// ---------------------------------------------------------------------------
+// K-element ("stream"): copy-tensor / hyperedge products, Khatri-Rao, Hadamard, traces, small-K
+// steps.  HBM-bound gather-multiply: the output index space is (hi, lo, n) with n running along C's
+// unit-stride label; one thread produces V consecutive n (one 16-byte store), consecutive lanes
+// consecutive vectors, so C is written - and every operand that is unit-stride along n is read -
+// in full cache lines; an operand that does not carry the label is a per-thread broadcast.  No
+// identity tensor exists anywhere: a copy tensor is only the shared (hi/lo/n) index.
+// Operands are divided by their producer's rescale on load, exactly like the reference's
+// stabilize() output feeding the next step: bit-identical when the K sum is exact.
+// ---------------------------------------------------------------------------
+template <typename T, int V>
+struct VecOf;
+template <> struct VecOf<float, 4> { typedef float4 type; };
+template <> struct VecOf<double, 2> { typedef double2 type; };
+template <typename T> struct VecOf<T, 1> { typedef T type; };
+
+template <typename T, int V>
+__device__ __forceinline__ void load_vec(const T* __restrict__ p, int stride_n, T (&out)[V]) {
+  if constexpr (V == 1) {
+    out[0] = p[0];
+  } else {
+    if (stride_n == 0) {
+      const T x = p[0];
+#pragma unroll
+      for (int v = 0; v < V; ++v) out[v] = x;
+    } else {
+      typedef typename VecOf<T, V>::type VT;
+      const VT x = *reinterpret_cast<const VT*>(p);
+      const T* e = reinterpret_cast<const T*>(&x);
+#pragma unroll
+      for (int v = 0; v < V; ++v) out[v] = e[v];
+    }
+  }
+}
+
+template <typename T, int V, int U>
+__global__ __launch_bounds__(256) void k_stream(StepArgs a) {
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const bool divA = sA != (T)1, divB = sB != (T)1;
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const T* __restrict__ A = (const T*)tp[a.idA];
+  const T* __restrict__ B = (const T*)tp[a.idB];
+  T* __restrict__ C = (T*)tp[a.idC];
+  // one item = U vectors of V elements of one output row (hi, lo): columns c, c + S, ..., c + (U-1) S
+  // with S = vectors per row / U, so the row's table lookups and broadcast operands are paid once
+  // per U*V outputs while every store instruction of a wave still covers a contiguous segment.
+  const uint32_t nq_per = (uint32_t)((a.Nv + V - 1) / V);
+  const uint32_t S = nq_per / U;                 // U divides nq_per (checked on the host)
+  const uint32_t items = (uint32_t)a.H * (uint32_t)a.L * S;  // < 2^31
+  const FastDiv dq = a.dNq;                      // divisor S
+  const bool kone = a.K == 1;                    // pure product: k-offset tables hold a single 0
+  double absv = 0;
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += stride) {
+    const uint32_t row = dq.div(it);
+    const int c0 = (int)(it - row * S) * V;
+    const int h = (int)a.dL.div(row);
+    const int l = (int)(row - (uint32_t)h * (uint32_t)a.L);
+    const T* pa = A + a.ohA[h] + a.olA[l] + c0 * a.sAn;
+    const T* pb = B + a.ohB[h] + a.olB[l] + c0 * a.sBn;
+    T* pc = C + (size_t)row * a.Nv + c0;         // C is contiguous in (hi, lo, n) order
+    T acc[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[u][v] = 0;
+    const int stepA = (int)S * V * a.sAn, stepB = (int)S * V * a.sBn;
+    for (int k = 0; k < a.K; ++k) {
+      const int ka = kone ? 0 : a.okA[k], kb = kone ? 0 : a.okB[k];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        T av[V], bv[V];
+        load_vec<T, V>(pa + ka + u * stepA, a.sAn, av);
+        load_vec<T, V>(pb + kb + u * stepB, a.sBn, bv);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const T x = divA ? av[v] / sA : av[v];
+          const T y = divB ? bv[v] / sB : bv[v];
+          acc[u][v] = fma(x, y, acc[u][v]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (V == 1) {
+        pc[u * S] = acc[u][0];
+      } else {
+        typedef typename VecOf<T, V>::type VT;
+        VT o;
+        T* e = reinterpret_cast<T*>(&o);
+#pragma unroll
+        for (int v = 0; v < V; ++v) e[v] = acc[u][v];
+        *reinterpret_cast<VT*>(pc + u * S * V) = o;
+      }
+      T part = 0;
+#pragma unroll
+      for (int v = 0; v < V; ++v) part += fabs(acc[u][v]);
+      absv += (double)part;
+    }
+  }
+  const double tot = block_sum(absv, red);
+  if (threadIdx.x == 0) a.partC[(size_t)r * a.partC_stride + blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// K-rowdot: one WAVE per output element, the 64 lanes stride a unit-stride K (coalesced
+// 256-byte reads), xor-butterfly reduction.  GEMV / batched-dot shaped steps.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_rowdot(StepArgs a) {
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const bool divA = sA != (T)1, divB = sB != (T)1;
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const T* __restrict__ A = (const T*)tp[a.idA];
+  const T* __restrict__ B = (const T*)tp[a.idB];
+  T* __restrict__ C = (T*)tp[a.idC];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t outs = (uint32_t)a.H * (uint32_t)a.L * (uint32_t)a.Nv;
+  double mine = 0;
+  for (uint32_t o = blockIdx.x * 4u + w; o < outs; o += gridDim.x * 4u) {  // wave-uniform
+    const uint32_t o2 = a.dNv.div(o);
+    const int n = (int)(o - o2 * (uint32_t)a.Nv);
+    const int h = (int)a.dL.div(o2);
+    const int l = (int)(o2 - (uint32_t)h * (uint32_t)a.L);
+    const T* pa = A + a.ohA[h] + a.olA[l] + (int64_t)n * a.sAn;
+    const T* pb = B + a.ohB[h] + a.olB[l] + (int64_t)n * a.sBn;
+    T acc0 = 0, acc1 = 0;
+    int k = lane;
+    for (; k + 64 < a.K; k += 128) {
+      const T x0 = pa[a.okA[k]], y0 = pb[a.okB[k]];
+      const T x1 = pa[a.okA[k + 64]], y1 = pb[a.okB[k + 64]];
+      acc0 = fma(divA ? x0 / sA : x0, divB ? y0 / sB : y0, acc0);
+      acc1 = fma(divA ? x1 / sA : x1, divB ? y1 / sB : y1, acc1);
+    }
+    if (k < a.K) {
+      const T x0 = pa[a.okA[k]], y0 = pb[a.okB[k]];
+      acc0 = fma(divA ? x0 / sA : x0, divB ? y0 / sB : y0, acc0);
+    }
+    double v = (double)acc0 + (double)acc1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const T res = (T)v;
+    if (lane == 0) C[a.ohC[h] + a.olC[l] + n] = res;
+    mine += (double)fabs(res);
+  }
+  if (lane == 0) red[w] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    a.partC[(size_t)r * a.partC_stride + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// ---------------------------------------------------------------------------
+// K-dot: one workgroup per output element, K split over 256 lanes.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_dot(StepArgs a) {
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const T* __restrict__ A = (const T*)tp[a.idA];
+  const T* __restrict__ B = (const T*)tp[a.idB];
+  T* __restrict__ C = (T*)tp[a.idC];
+  const int o = blockIdx.x;
+  const int n = o % a.N;
+  const int q = o / a.N;
+  const int m = q % a.M;
+  const int b = q / a.M;
+  const T* pa = A + a.obA[b] + a.omA[m];
+  const T* pb = B + a.obB[b] + a.onB[n];
+  T acc = 0;
+  for (int k = threadIdx.x; k < a.K; k += 256) acc = fma(pa[a.okA[k]] / sA, pb[a.okB[k]] / sB, acc);
+  const T tot = (T)block_sum((double)acc, red);
+  if (threadIdx.x == 0) {
+    const T v = tot;
+    C[a.obC[b] + a.omC[m] + a.onC[n]] = v;
+    a.partC[(size_t)r * a.partC_stride + o] = (double)fabs(v);
+  }
+}
+
+// Collapse > 64 per-workgroup partials into one, in a fixed order.
+__global__ __launch_bounds__(256) void k_collapse(const double* scratch, int blocks, double* part) {
+  __shared__ double red[4];
+  const int r = blockIdx.x;
+  const double* src = scratch + (size_t)r * blocks;
+  double v = 0;
+  for (int i = threadIdx.x; i < blocks; i += 256) v += src[i];
+  const double tot = block_sum(v, red);
+  if (threadIdx.x == 0) part[(size_t)r * kMaxPartials] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// Finishing passes.  k_scales: one wave per (step, replica) turns the step's partials into its
+// rescale factor (0.0 = not rescaled) and log(rescale) evaluated in the tensor dtype
+// (reference einsum.py:97-106).  k_finalize: normalise the final tensor and sum the logs.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_scales(FinalArgs f, double* __restrict__ logs) {
+  const int r = blockIdx.y;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= f.n_steps) return;  // whole wave exits together
+  bool cond = false;
+  T sc = (T)1;
+  if (f.stabilize)
+    sc = producer_scale<T>(f.partials + (size_t)s * f.R * kMaxPartials, f.stepP[s], f.stepNumel[s],
+                           f.min_norm, r, &cond);
+  if ((threadIdx.x & 63) == 0) {
+    f.rescales[(size_t)r * f.n_steps + s] = cond ? (double)sc : 0.0;
+    logs[(size_t)r * f.n_steps + s] = cond ? (double)log(sc) : 0.0;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_finalize(FinalArgs f, const double* __restrict__ logs) {
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  if (blockIdx.x == 0) {
+    double v = 0;
+    for (int s = threadIdx.x; s < f.n_steps; s += 256) v += logs[(size_t)r * f.n_steps + s];
+    const double tot = block_sum(v, red);
+    if (threadIdx.x == 0) f.log_scale[r] = tot;
+  }
+  if (!f.stabilize) return;
+  const double rl = f.rescales[(size_t)r * f.n_steps + f.n_steps - 1];
+  if (rl == 0.0) return;  // last step was not rescaled (norm <= min_norm): tensor unchanged
+  const T s_last = (T)rl;
+  T* out = (T*)f.ptrs[(size_t)r * f.n_tensors + f.id_out];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < f.out_numel; i += (int64_t)gridDim.x * 256)
+    out[i] = out[i] / s_last;
+}
+
+// ---------------------------------------------------------------------------
+// K-chain: persistent small-tensor DAG walker.  One workgroup per replica executes EVERY step of
+// the plan in order (reference loop einsum.py:341-391) - no per-step launch, rescale factors of
+// all produced tensors kept in LDS.  Same arithmetic as k_element (operands divided by their
+// producer's rescale on load), so results are bit-identical to the per-step path.
+// ---------------------------------------------------------------------------
+struct ChainStep {
+  const int32_t *obA, *obB, *obC, *omA, *omC, *onB, *onC, *okA, *okB;
+  double numelC;
+  int32_t Bt, M, N, K;
+  int32_t idA, idB, idC;
+  int32_t prodA, prodB;  // producing step of each operand, -1 for inputs
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_chain(const ChainStep* __restrict__ steps, int n_steps,
+                                               void* const* ptrs, int n_tensors, double* partials,
+                                               int R, double min_norm, int stabilize) {
+  __shared__ double red[4];
+  __shared__ T sc[kChainMaxSteps];
+  const int r = blockIdx.x;
+  void* const* tp = ptrs + (size_t)r * n_tensors;
+  for (int s = 0; s < n_steps; ++s) {
+    const ChainStep d = steps[s];
+    const T sA = d.prodA >= 0 ? sc[d.prodA] : (T)1;
+    const T sB = d.prodB >= 0 ? sc[d.prodB] : (T)1;
+    const T* __restrict__ A = (const T*)tp[d.idA];
+    const T* __restrict__ B = (const T*)tp[d.idB];
+    T* __restrict__ C = (T*)tp[d.idC];
+    const int total = d.Bt * d.M * d.N;
+    double absv = 0;
+    for (int o = threadIdx.x; o < total; o += 256) {
+      const int n = o % d.N;
+      const int q = o / d.N;
+      const int m = q % d.M;
+      const int b = q / d.M;
+      const T* pa = A + d.obA[b] + d.omA[m];
+      const T* pb = B + d.obB[b] + d.onB[n];
+      T acc = 0;
+      for (int k = 0; k < d.K; ++k) acc = fma(pa[d.okA[k]] / sA, pb[d.okB[k]] / sB, acc);
+      C[d.obC[b] + d.omC[m] + d.onC[n]] = acc;
+      absv += (double)fabs(acc);
+    }
+    // the barriers inside block_sum also order this step's stores before the next step's loads
+    const double tot = block_sum(absv, red);
+    if (threadIdx.x == 0) {
+      partials[((size_t)s * R + r) * kMaxPartials] = tot;
+      const T norm = (T)tot;
+      sc[s] = (stabilize && norm > (T)min_norm) ? norm / (T)d.numelC : (T)1;
+    }
+    __syncthreads();
+  }
+}
+
+
+}  // namespace ctn
