@@ -61,6 +61,8 @@ struct Exec {
   bool ptrs_valid = false;
   double* d_partials = nullptr;
   double* d_scratch = nullptr;
+  float* d_slab = nullptr;          // split-K partial tiles (latency mode), sized at creation
+  std::vector<int> step_partials;   // abs-sum partials per replica of every step (plan value unless split-K)
   double* d_log = nullptr;
   double* d_resc = nullptr;
   double* d_logs = nullptr;
@@ -81,7 +83,7 @@ struct Exec {
 
   ~Exec() {
     (void)hipSetDevice(device);
-    for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch,
+    for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch, (void*)d_slab,
                     (void*)d_log, (void*)d_resc, (void*)d_logs, (void*)d_chain, d_ones, (void*)d_stepP, (void*)d_stepNumel,
                     (void*)d_stage_in, (void*)d_stage_out})
       if (p) (void)hipFree(p);
@@ -134,6 +136,38 @@ static void launch_mfma(int ma, int mb, int tile_n, dim3 grid, hipStream_t st, c
   }
 }
 
+// Latency mode (see k_mfma_f32_sk): chosen when the 128-wide tiles of a step cannot occupy half the
+// chip.  Returns the number of K splits (0 = use the throughput kernel).  CTN_SPLITK=0 disables,
+// CTN_SPLITK=1 forces it for every eligible step (tests).
+static int splitk_splits(const Step& st, int R, int n_cu, int dtype) {
+  static const int mode = [] { const char* e = getenv("CTN_SPLITK"); return e ? atoi(e) : -1; }();
+  if (mode == 0 || dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.collapse || st.K < 128) return 0;
+  static const int max_tiles = [] { const char* e = getenv("CTN_SPLITK_MAX"); return e ? atoi(e) : 0; }();
+  const int64_t limit = max_tiles > 0 ? max_tiles : n_cu / 2;
+  if (mode != 1 && (int64_t)st.blocks * R > limit) return 0;
+  const int64_t tiles64 = st.Bt * ((st.M + 63) / 64) * ((st.N + 63) / 64) * R;
+  int64_t S = (2 * (int64_t)n_cu + tiles64 - 1) / tiles64;   // aim at ~2 small workgroups per CU
+  S = std::max<int64_t>(1, std::min<int64_t>(S, st.K / 64));
+  return (int)S;
+}
+
+template <int MA>
+static void launch_sk_b(int mb, dim3 grid, hipStream_t st, const StepArgs& a, const SplitKArgs& sk) {
+  switch (mb) {
+    case 1: hipLaunchKernelGGL((k_mfma_f32_sk<MA, 1>), grid, dim3(256), 0, st, a, sk); break;
+    case 2: hipLaunchKernelGGL((k_mfma_f32_sk<MA, 2>), grid, dim3(256), 0, st, a, sk); break;
+    default: hipLaunchKernelGGL((k_mfma_f32_sk<MA, 0>), grid, dim3(256), 0, st, a, sk); break;
+  }
+}
+
+static void launch_sk(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a, const SplitKArgs& sk) {
+  switch (ma) {
+    case 1: launch_sk_b<1>(mb, grid, st, a, sk); break;
+    case 2: launch_sk_b<2>(mb, grid, st, a, sk); break;
+    default: launch_sk_b<0>(mb, grid, st, a, sk); break;
+  }
+}
+
 static int exec_launch_all(Exec* E) {
   const Plan& P = *E->plan;
   const int R = E->R;
@@ -166,7 +200,7 @@ static int exec_launch_all(Exec* E) {
       if (id >= P.n_inputs && P.stabilize) {
         const int ps = P.tensors[id].producer;
         *p = E->d_partials + (size_t)ps * R * kMaxPartials;
-        *cnt = P.steps[ps].partials;
+        *cnt = E->step_partials[ps];
         *numel = (double)P.tensors[id].numel;
       }
     };
@@ -200,6 +234,20 @@ static int exec_launch_all(Exec* E) {
       case CTN_KERNEL_MFMA_F32: {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
+        if (const int S = E->d_slab ? splitk_splits(st, R, E->n_cu, P.dtype) : 0) {
+          SplitKArgs sk;
+          sk.slab = E->d_slab;
+          sk.numelC = P.tensors[st.out].numel;
+          sk.S = S;
+          sk.kchunk = (int32_t)(((st.K + S - 1) / S + 31) / 32 * 32);
+          sk.S = (int32_t)((st.K + sk.kchunk - 1) / sk.kchunk);  // drop empty trailing splits
+          sk.tiles_m = (int32_t)((st.M + 63) / 64);
+          sk.tiles_n = (int32_t)((st.N + 63) / 64);
+          sk.tiles_per_replica = (int32_t)(st.Bt * sk.tiles_m * sk.tiles_n);
+          launch_sk(st.modeA, st.modeB, dim3((unsigned)((int64_t)sk.tiles_per_replica * sk.S * R)), E->stream, a, sk);
+          hipLaunchKernelGGL(k_splitk_reduce, dim3(E->step_partials[s], R), dim3(256), 0, E->stream, a, sk);
+          break;
+        }
         a.tiles_n = (int32_t)((st.N + st.tileN - 1) / st.tileN);
         if (getenv("CTN_DEBUG_STAMPS")) {
           if (E->dbg_tiles < (size_t)total) {
@@ -414,7 +462,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   if (!x) { g_err = "out of host memory"; return CTN_OOM; }
   Exec& E = x->e;
   const Plan& P = plan->p;
-  E.plan = &P; E.device = device; E.R = replicas; E.n_cu = n_cu > 0 ? n_cu : 256;
+  E.plan = &P; E.device = device; E.R = replicas; E.n_cu = n_cu > 0 ? n_cu : 256; E.n_cu = n_cu > 0 ? n_cu : 256;
   E.n_tensors = P.n_inputs + P.n_steps + 1;
   auto fail = [&](int code) { delete x; return code; };
 #define HIPCHECK_X(expr)                                                        \
@@ -435,6 +483,21 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   HIPCHECK_X(hipMalloc((void**)&E.d_partials, (size_t)P.n_steps * replicas * kMaxPartials * 8));
   HIPCHECK_X(hipMemset(E.d_partials, 0, (size_t)P.n_steps * replicas * kMaxPartials * 8));
   HIPCHECK_X(hipMalloc((void**)&E.d_scratch, (size_t)replicas * std::max<int64_t>(P.max_collapse_blocks, 1) * 8));
+  {
+    size_t slab_elems = 0;   // split-K scratch: S slabs shaped like the step's output, per replica
+    for (const Step& st : P.steps)
+      if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype))
+        slab_elems = std::max(slab_elems, (size_t)S * (size_t)P.tensors[st.out].numel * (size_t)replicas);
+    if (slab_elems) HIPCHECK_X(hipMalloc((void**)&E.d_slab, slab_elems * sizeof(float)));
+  }
+  // partial counts: the split-K reduce pass spreads over up to 64 workgroups per replica
+  E.step_partials.resize(P.n_steps);
+  for (int s = 0; s < P.n_steps; ++s) {
+    const Step& st = P.steps[s];
+    E.step_partials[s] = st.partials;
+    if (E.d_slab && splitk_splits(st, replicas, E.n_cu, P.dtype))
+      E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxPartials, P.tensors[st.out].numel / 1024));
+  }
   HIPCHECK_X(hipMalloc((void**)&E.d_log, (size_t)replicas * 8));
   HIPCHECK_X(hipMalloc((void**)&E.d_resc, (size_t)replicas * P.n_steps * 8));
   HIPCHECK_X(hipMalloc((void**)&E.d_logs, (size_t)replicas * P.n_steps * 8));
@@ -446,7 +509,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   }
   std::vector<int32_t> sp(P.n_steps);
   std::vector<double> sn(P.n_steps);
-  for (int s = 0; s < P.n_steps; ++s) { sp[s] = P.steps[s].partials; sn[s] = (double)P.tensors[P.steps[s].out].numel; }
+  for (int s = 0; s < P.n_steps; ++s) { sp[s] = E.step_partials[s]; sn[s] = (double)P.tensors[P.steps[s].out].numel; }
   HIPCHECK_X(hipMalloc((void**)&E.d_stepP, P.n_steps * 4));
   HIPCHECK_X(hipMalloc((void**)&E.d_stepNumel, P.n_steps * 8));
   HIPCHECK_X(hipMemcpy(E.d_stepP, sp.data(), P.n_steps * 4, hipMemcpyHostToDevice));

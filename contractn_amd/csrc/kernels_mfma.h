@@ -344,6 +344,160 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
 }
 
 // ---------------------------------------------------------------------------
+// K-mfma-f32-sk: LATENCY mode for launches that cannot fill the chip with 128-wide tiles (a single
+// network or a few replicas: a 128x128x1024 tile is ~55 us of matrix-pipe time on ONE CU while
+// 250 CUs idle).  64x64 tiles, 4 waves of 32x32 (one accumulator each), BK = 32, and the K range
+// split S ways across workgroups; every split writes its un-scaled partial tile into slab s of a
+// scratch buffer laid out like C, and k_splitk_reduce sums the S slabs in a FIXED order (bit-
+// reproducible, no atomics), applies the lazy rescale and emits the abs-sum partials.
+// ---------------------------------------------------------------------------
+struct SplitKArgs {
+  float* slab;        // [R][S][numelC]
+  int64_t numelC;
+  int32_t S, kchunk;  // splits and K elements per split (multiple of 32)
+  int32_t tiles_m, tiles_n, tiles_per_replica;  // 64-wide tiles
+};
+
+template <int MA, int MB>
+__global__ __launch_bounds__(256) void k_mfma_f32_sk(StepArgs a, SplitKArgs sk) {
+  constexpr int T = 64, BK = 32;
+  using LA = TileLoader<MA, BK, T>;
+  using LB = TileLoader<MB, BK, T>;
+  constexpr int SZA = LA::kSize, SZB = LB::kSize;
+  __shared__ __attribute__((aligned(16))) float smem[2 * SZA + 2 * SZB];
+  __shared__ int s_omC[T], s_onC[T];
+  float* sA = smem;
+  float* sB = smem + 2 * SZA;
+
+  const int tid = threadIdx.x;
+  const int per_rep = sk.tiles_per_replica * sk.S;
+  const int pid = blockIdx.x;
+  const int r = pid / per_rep;
+  const int rem = pid - r * per_rep;
+  const int t = rem / sk.S;
+  const int s = rem - t * sk.S;
+  const int tiles_mn = sk.tiles_m * sk.tiles_n;
+  const int b = t / tiles_mn;
+  const int tt = t - b * tiles_mn;
+  const int m0 = (tt / sk.tiles_n) * T;
+  const int n0 = (tt % sk.tiles_n) * T;
+  const int kbeg = s * sk.kchunk;
+  const int kend = min(a.K, kbeg + sk.kchunk);   // this split's K range; masks use kend
+
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
+  const float* __restrict__ B = (const float*)tp[a.idB] + a.obB[b];
+  float* __restrict__ C = sk.slab + ((size_t)r * sk.S + s) * sk.numelC + a.obC[b];
+
+  if (tid < T) s_omC[tid] = a.omC[m0 + tid];
+  else if (tid < 2 * T) s_onC[tid - T] = a.onC[n0 + tid - T];
+
+  LA la;
+  LB lb;
+  la.init(a.omA, m0, a.M, tid);
+  lb.init(a.onB, n0, a.N, tid);
+
+  const int lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+  const int l31 = lane & 31, h = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+  const int nkt = (kend - kbeg + BK - 1) / BK;   // >= 1 (host guarantees kbeg < K)
+  la.tab(a.okA, kbeg, tid);
+  lb.tab(a.okB, kbeg, tid);
+  la.load(A);
+  lb.load(B);
+  la.tab(a.okA, kbeg + BK, tid);
+  lb.tab(a.okB, kbeg + BK, tid);
+  la.template store<false>(sA, kbeg, kend, tid);
+  lb.template store<false>(sB, kbeg, kend, tid);
+  __syncthreads();
+
+  const int fa = LA::idx(wm + l31, h), fb = LB::idx(wn + l31, h);
+  constexpr int stepA = MA == 2 ? 2 : 2 * T;
+  constexpr int stepB = MB == 2 ? 2 : 2 * T;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      la.load(A);
+      lb.load(B);
+      la.tab(a.okA, kbeg + (kt + 2) * BK, tid);
+      lb.tab(a.okB, kbeg + (kt + 2) * BK, tid);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* cA = sA + cur * SZA;
+    const float* cB = sB + cur * SZB;
+    float xa[2], xb[2];
+    xa[0] = cA[fa]; xb[0] = cB[fb];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int c = kk & 1, nx = c ^ 1;
+      if (kk + 1 < BK / 2) {
+        xa[nx] = cA[fa + (kk + 1) * stepA];
+        xb[nx] = cB[fb + (kk + 1) * stepB];
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[c], xb[c], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      la.template store<false>(sA + (cur ^ 1) * SZA, kbeg + (kt + 1) * BK, kend, tid);
+      lb.template store<false>(sB + (cur ^ 1) * SZB, kbeg + (kt + 1) * BK, kend, tid);
+    }
+    __syncthreads();
+  }
+
+  const int col = wn + l31;
+  if (n0 + col < a.N) {
+    const int offn = s_onC[col];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (m0 + row < a.M) C[s_omC[row] + offn] = acc[e];
+    }
+  }
+}
+
+// Sum the S partial slabs in order, apply the producers' rescale, write C and the abs-sum partials
+// (exactly P = the step's planned partial count of workgroups per replica, so consumers are unchanged).
+__global__ __launch_bounds__(256) void k_splitk_reduce(StepArgs a, SplitKArgs sk) {
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const float iA = 1.0f / scA, iB = 1.0f / scB;
+  float* __restrict__ C = (float*)a.ptrs[(size_t)r * a.n_tensors + a.idC];
+  const float* __restrict__ slab = sk.slab + (size_t)r * sk.S * sk.numelC;
+  const int64_t per = ((sk.numelC + gridDim.x - 1) / gridDim.x + 3) & ~(int64_t)3;  // multiple of 4
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = min(sk.numelC, lo + per);
+  float asum = 0.f;
+  if ((sk.numelC & 3) == 0) {  // 16-byte vectors (slabs and C are 256-byte aligned)
+    for (int64_t i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+      float4 v = *reinterpret_cast<const float4*>(slab + i);
+      for (int s = 1; s < sk.S; ++s) {
+        const float4 x = *reinterpret_cast<const float4*>(slab + (size_t)s * sk.numelC + i);
+        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+      }
+      v.x = (v.x * iA) * iB; v.y = (v.y * iA) * iB; v.z = (v.z * iA) * iB; v.w = (v.w * iA) * iB;
+      *reinterpret_cast<float4*>(C + i) = v;
+      asum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+    }
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+      float v = slab[i];
+      for (int s = 1; s < sk.S; ++s) v += slab[(size_t)s * sk.numelC + i];
+      v = (v * iA) * iB;
+      C[i] = v;
+      asum += fabsf(v);
+    }
+  }
+  const double tot = block_sum((double)asum, red);
+  if (threadIdx.x == 0) a.partC[(size_t)r * a.partC_stride + blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------
 // K-mfma-f64: 64x64 workgroup tile, 4 waves (2x2), each wave 32x32 = 2x2
 // v_mfma_f64_16x16x4_f64 accumulators, BK = 16, table-driven gather loads coalesced along the
 // free index, LDS image [k][80] (row stride = 640 B = 32 banks mod 64: the two k rows a 32-lane
