@@ -40,25 +40,18 @@ __device__ __forceinline__ void load_vec(const T* __restrict__ p, int stride_n, 
   }
 }
 
-template <typename T, int V, int U>
-__global__ __launch_bounds__(256) void k_stream(StepArgs a) {
-  __shared__ double red[4];
-  const int r = blockIdx.y;
-  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
-  const bool divA = sA != (T)1, divB = sB != (T)1;
-  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
-  const T* __restrict__ A = (const T*)tp[a.idA];
-  const T* __restrict__ B = (const T*)tp[a.idB];
-  T* __restrict__ C = (T*)tp[a.idC];
-  // one item = U vectors of V elements of one output row (hi, lo): columns c, c + S, ..., c + (U-1) S
-  // with S = vectors per row / U, so the row's table lookups and broadcast operands are paid once
-  // per U*V outputs while every store instruction of a wave still covers a contiguous segment.
+// Item loop of k_stream.  DA / DB (does operand A / B need dividing by its producer's rescale?) are
+// template flags chosen ONCE per workgroup, so the loop body has no per-element branches and all
+// 2U loads of an item are issued back to back before any arithmetic.
+template <typename T, int V, int U, bool DA, bool DB>
+__device__ __forceinline__ double stream_items(const StepArgs& a, const T* __restrict__ A, const T* __restrict__ B,
+                                               T* __restrict__ C, T sA, T sB) {
   const uint32_t nq_per = (uint32_t)((a.Nv + V - 1) / V);
   const uint32_t S = nq_per / U;                 // U divides nq_per (checked on the host)
   const uint32_t items = (uint32_t)a.H * (uint32_t)a.L * S;  // < 2^31
   const FastDiv dq = a.dNq;                      // divisor S
   const bool kone = a.K == 1;                    // pure product: k-offset tables hold a single 0
+  const int stepA = (int)S * V * a.sAn, stepB = (int)S * V * a.sBn;
   double absv = 0;
   const uint32_t stride = gridDim.x * 256u;
   for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += stride) {
@@ -74,21 +67,23 @@ __global__ __launch_bounds__(256) void k_stream(StepArgs a) {
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < V; ++v) acc[u][v] = 0;
-    const int stepA = (int)S * V * a.sAn, stepB = (int)S * V * a.sBn;
-    for (int k = 0; k < a.K; ++k) {
+    const int nk = kone ? 1 : a.K;
+    for (int k = 0; k < nk; ++k) {
       const int ka = kone ? 0 : a.okA[k], kb = kone ? 0 : a.okB[k];
+      T av[U][V], bv[U][V];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        T av[V], bv[V];
-        load_vec<T, V>(pa + ka + u * stepA, a.sAn, av);
-        load_vec<T, V>(pb + kb + u * stepB, a.sBn, bv);
+        load_vec<T, V>(pa + ka + u * stepA, a.sAn, av[u]);
+        load_vec<T, V>(pb + kb + u * stepB, a.sBn, bv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          const T x = divA ? av[v] / sA : av[v];
-          const T y = divB ? bv[v] / sB : bv[v];
+          const T x = DA ? av[u][v] / sA : av[u][v];
+          const T y = DB ? bv[u][v] / sB : bv[u][v];
           acc[u][v] = fma(x, y, acc[u][v]);
         }
-      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -108,6 +103,29 @@ __global__ __launch_bounds__(256) void k_stream(StepArgs a) {
       absv += (double)part;
     }
   }
+  return absv;
+}
+
+// one item = U vectors of V elements of one output row (hi, lo): columns c, c + S, ..., c + (U-1) S
+// with S = vectors per row / U, so the row's table lookups and broadcast operands are paid once
+// per U*V outputs while every store instruction of a wave still covers a contiguous segment.
+template <typename T, int V, int U>
+__global__ __launch_bounds__(256) void k_stream(StepArgs a) {
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const T* __restrict__ A = (const T*)tp[a.idA];
+  const T* __restrict__ B = (const T*)tp[a.idB];
+  T* __restrict__ C = (T*)tp[a.idC];
+  // x / 1 == x exactly, so the division is skipped for network inputs and un-rescaled tensors
+  const bool da = sA != (T)1, db = sB != (T)1;
+  double absv;
+  if (!da && !db) absv = stream_items<T, V, U, false, false>(a, A, B, C, sA, sB);
+  else if (da && !db) absv = stream_items<T, V, U, true, false>(a, A, B, C, sA, sB);
+  else if (!da && db) absv = stream_items<T, V, U, false, true>(a, A, B, C, sA, sB);
+  else absv = stream_items<T, V, U, true, true>(a, A, B, C, sA, sB);
   const double tot = block_sum(absv, red);
   if (threadIdx.x == 0) a.partC[(size_t)r * a.partC_stride + blockIdx.x] = tot;
 }
