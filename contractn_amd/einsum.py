@@ -17,6 +17,7 @@ error behaviour:
 
 There is no CPU fallback: without the HIP library or a GPU, ``contract`` raises.
 """
+from collections import OrderedDict
 from functools import lru_cache
 
 import numpy as np
@@ -131,12 +132,34 @@ def _native_plan(contract_list, shapes, dtype_name):
     return engine.Plan(dtype_name, in_labels, shapes, steps, stabilize=True, min_norm=MIN_NORM)
 
 
-def _executor_for(plan, replicas=1):
-    cache = plan.__dict__.setdefault("_executors", {})
-    ex = cache.get(replicas)
-    if ex is None:
-        ex = cache[replicas] = engine.Executor(plan, replicas=replicas)
+# Executors own device memory (workspace, tables, staging).  They are kept in a small LRU so that a
+# process contracting many differently-shaped networks does not accumulate workspaces without bound;
+# an evicted executor frees its device memory immediately (the plan itself is host-only and cheap).
+_EXECUTOR_LRU = OrderedDict()
+MAX_CACHED_EXECUTORS = 16
+
+
+def _executor_for(plan, replicas=1, device=0, stream=None):
+    key = (id(plan), replicas, device, stream)
+    ex = _EXECUTOR_LRU.get(key)
+    if ex is not None:
+        _EXECUTOR_LRU.move_to_end(key)
+        return ex
+    ex = engine.Executor(plan, replicas=replicas, device=device, stream=stream)
+    _EXECUTOR_LRU[key] = ex
+    while len(_EXECUTOR_LRU) > MAX_CACHED_EXECUTORS:
+        _, old = _EXECUTOR_LRU.popitem(last=False)
+        old.close()
     return ex
+
+
+def clear_caches():
+    """Drop every cached executor (device memory), native plan and contraction path."""
+    while _EXECUTOR_LRU:
+        _, ex = _EXECUTOR_LRU.popitem()
+        ex.close()
+    _native_plan.cache_clear()
+    _contract_path.cache_clear()
 
 
 # ---------------------------------------------------------------------------
@@ -234,12 +257,8 @@ def _run_torch(plan, operands, dtype):
     # views into a larger storage may start at an odd offset: vector loads need 16-byte alignment
     ops = [o.clone() if o.data_ptr() % 16 else o for o in ops]
     out = torch.empty(plan.out_shape, dtype=tdt, device=dev)
-    cache = plan.__dict__.setdefault("_torch_executors", {})
     stream = torch.cuda.current_stream(dev).cuda_stream
-    key = (dev.index or 0, stream)
-    ex = cache.get(key)
-    if ex is None:
-        ex = cache[key] = engine.Executor(plan, replicas=1, device=dev.index or 0, stream=stream)
+    ex = _executor_for(plan, 1, device=dev.index or 0, stream=stream)
     ex.enqueue([o.data_ptr() for o in ops], [out.data_ptr()])
     _dev_log, resc = ex.fetch()
     log_scale = accumulate_log_scale(resc[0], dtype)

@@ -184,3 +184,19 @@ def test_make_contract_fun_accepts_new_params_each_call():
         np.testing.assert_allclose(fun(p, ()), p[0] @ p[1], rtol=1e-12)
     x.tensor = np.ones((6, 5))
     np.testing.assert_allclose(tn.contract(), np.ones((6, 5)) @ tn.params[1], rtol=1e-12)
+
+
+def test_executor_cache_is_bounded_and_clearable():
+    import contractn_amd
+    from contractn_amd import einsum as EE
+
+    contractn_amd.clear_caches()
+    rng = np.random.default_rng(0)
+    for n in range(3, 3 + EE.MAX_CACHED_EXECUTORS + 5):
+        a, b = rng.standard_normal((n, 4)), rng.standard_normal((4, n))
+        np.testing.assert_allclose(contract("ab,bc->ac", a, b), a @ b, rtol=1e-12)
+    assert len(EE._EXECUTOR_LRU) == EE.MAX_CACHED_EXECUTORS
+    contractn_amd.clear_caches()
+    assert len(EE._EXECUTOR_LRU) == 0
+    a = rng.standard_normal((5, 4))
+    np.testing.assert_allclose(contract("ab,cb->ac", a, a), a @ a.T, rtol=1e-12)
