@@ -257,7 +257,12 @@ def _run_torch(plan, operands, dtype):
     # views into a larger storage may start at an odd offset: vector loads need 16-byte alignment
     ops = [o.clone() if o.data_ptr() % 16 else o for o in ops]
     out = torch.empty(plan.out_shape, dtype=tdt, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    tstream = torch.cuda.current_stream(dev)
+    stream = tstream.cuda_stream
+    if not stream:
+        # torch is on the legacy default stream (handle 0), which cannot be handed to the executor:
+        # it runs on its own non-blocking stream, so wait for the producers of the operands first
+        tstream.synchronize()
     ex = _executor_for(plan, 1, device=dev.index or 0, stream=stream)
     ex.enqueue([o.data_ptr() for o in ops], [out.data_ptr()])
     _dev_log, resc = ex.fetch()
