@@ -263,9 +263,16 @@ static int exec_launch_all(Exec* E) {
       case CTN_KERNEL_MFMA_F64: {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
-        a.tiles_m = (int32_t)((st.M + kTile64 - 1) / kTile64);
-        a.tiles_n = (int32_t)((st.N + kTile64 - 1) / kTile64);
-        hipLaunchKernelGGL(k_mfma_f64, dim3((unsigned)total), dim3(256), 0, E->stream, a);
+        a.tiles_m = (int32_t)((st.M + kTile64M - 1) / kTile64M);
+        a.tiles_n = (int32_t)((st.N + kTile64N - 1) / kTile64N);
+        const dim3 g((unsigned)total), b(256);
+#define CTN_F64(AA, BB) hipLaunchKernelGGL((k_mfma_f64<AA, BB>), g, b, 0, E->stream, a)
+        switch (st.modeA * 3 + st.modeB) {
+          case 0: CTN_F64(0, 0); break; case 1: CTN_F64(0, 1); break; case 2: CTN_F64(0, 2); break;
+          case 3: CTN_F64(1, 0); break; case 4: CTN_F64(1, 1); break; case 5: CTN_F64(1, 2); break;
+          case 6: CTN_F64(2, 0); break; case 7: CTN_F64(2, 1); break; default: CTN_F64(2, 2); break;
+        }
+#undef CTN_F64
         break;
       }
       case CTN_KERNEL_DOT:

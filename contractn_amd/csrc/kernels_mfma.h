@@ -498,21 +498,117 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(StepArgs a, SplitKArgs sk
 }
 
 // ---------------------------------------------------------------------------
-// K-mfma-f64: 64x64 workgroup tile, 4 waves (2x2), each wave 32x32 = 2x2
-// v_mfma_f64_16x16x4_f64 accumulators, BK = 16, table-driven gather loads coalesced along the
-// free index, LDS image [k][80] (row stride = 640 B = 32 banks mod 64: the two k rows a 32-lane
-// group reads fall on disjoint bank halves).  f64 C/D map (NOT the f32 one): col = lane & 15,
-// row = (lane >> 4) + 4 * reg.
+// K-mfma-f64: 128x64 workgroup tile, 4 waves (2x2), each wave 64x32 = 4x2
+// v_mfma_f64_16x16x4_f64 accumulators (64 registers), BK = 16, the same pipeline as the fp32
+// kernel: k-offset table entries two tiles ahead, unconditional 16-byte loads where an operand is
+// unit-stride (mode 1 along the free index, mode 2 along k; mode 0 = scalar gather), masks applied
+// when the staged tile is written to LDS, fragment reads one k-step ahead of the MFMAs.
+// LDS images are [k][rows + pad] with row strides of 144 / 80 doubles (= 32 banks mod 64), so the
+// two k rows a 32-lane group reads fall on disjoint bank halves.
+// f64 C/D map (NOT the f32 one): col = lane & 15, row = (lane >> 4) + 4 * reg.
 // ---------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_mfma_f64(StepArgs a) {
-  constexpr int T64 = kTile64, BK = 16, LD = 80, SZ = BK * LD;
-  __shared__ __attribute__((aligned(16))) double smem[4 * SZ + 8];
-  __shared__ int s_omC[T64], s_onC[T64];
+template <int MODE, int ROWS, int LD>
+struct TileLoaderD {
+  static constexpr int BK = 16;
+  static constexpr int NV = ROWS * BK / 256;                 // doubles staged per thread
+  static constexpr int VPR = ROWS / 2;                       // mode 1: double2 per k-row
+  static constexpr int RPP = 256 / VPR;                      // mode 1: k-rows per pass
+  static constexpr int KPP = 256 / ROWS;                     // mode 0: k-rows per pass
+  static constexpr int NT = MODE == 1 ? BK / RPP : (MODE == 2 ? 1 : NV);
+  static constexpr int NM = MODE == 2 ? NV / 2 : 1;
+  static constexpr int kSize = BK * LD;
+
+  double v[NV];
+  int kofs[NT];
+  int offm[NM];
+  bool okm[NM];
+
+  __device__ __forceinline__ void init(const int32_t* __restrict__ om, int m0, int M, int tid) {
+    if (MODE == 1) {
+      const int gm = m0 + (tid % VPR) * 2;
+      offm[0] = om[gm]; okm[0] = gm < M;
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const int gm = m0 + (tid + i * 256) / (BK / 2);
+        offm[i] = om[gm]; okm[i] = gm < M;
+      }
+    } else {
+      const int gm = m0 + tid % ROWS;
+      offm[0] = om[gm]; okm[0] = gm < M;
+    }
+  }
+  __device__ __forceinline__ void tab(const int32_t* __restrict__ ok, int k0, int tid) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + tid / VPR + RPP * i];
+    } else if (MODE == 2) {
+      kofs[0] = ok[k0 + (tid % (BK / 2)) * 2];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) kofs[i] = ok[k0 + tid / ROWS + KPP * i];
+    }
+  }
+  __device__ __forceinline__ void load(const double* __restrict__ base) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const double2 x = *reinterpret_cast<const double2*>(base + offm[0] + kofs[i]);
+        v[2 * i] = x.x; v[2 * i + 1] = x.y;
+      }
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const double2 x = *reinterpret_cast<const double2*>(base + offm[i] + kofs[0]);
+        v[2 * i] = x.x; v[2 * i + 1] = x.y;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) v[i] = base[offm[0] + kofs[i]];
+    }
+  }
+  __device__ __forceinline__ void store(double* __restrict__ s, int k0, int K, int tid) const {
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int kr = tid / VPR + RPP * i;
+        const bool in = okm[0] && (k0 + kr) < K;
+        *reinterpret_cast<double2*>(s + kr * LD + (tid % VPR) * 2) =
+            make_double2(in ? v[2 * i] : 0.0, in ? v[2 * i + 1] : 0.0);
+      }
+    } else if (MODE == 2) {
+      const int kc = (tid % (BK / 2)) * 2;
+      const bool kin = (k0 + kc) < K;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const bool in = okm[i] && kin;
+        const int row = (tid + i * 256) / (BK / 2);
+        s[kc * LD + row] = in ? v[2 * i] : 0.0;
+        s[(kc + 1) * LD + row] = in ? v[2 * i + 1] : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int kr = tid / ROWS + KPP * i;
+        s[kr * LD + tid % ROWS] = (okm[0] && (k0 + kr) < K) ? v[i] : 0.0;
+      }
+    }
+  }
+};
+
+template <int MA, int MB>
+__global__ __launch_bounds__(256, 2) void k_mfma_f64(StepArgs a) {
+  constexpr int TM = 128, TN = 64, BK = 16, LDA = 144, LDB = 80;
+  using LA = TileLoaderD<MA, TM, LDA>;
+  using LB = TileLoaderD<MB, TN, LDB>;
+  constexpr int SZA = LA::kSize, SZB = LB::kSize;
+  __shared__ __attribute__((aligned(16))) double smem[2 * SZA + 2 * SZB + 8];
+  __shared__ int s_omC[TM], s_onC[TN];
   double* sA = smem;
-  double* sB = smem + 2 * SZ;
-  double* red = smem + 4 * SZ;
+  double* sB = smem + 2 * SZA;
+  double* red = smem + 2 * SZA + 2 * SZB;
 
   const int tid = threadIdx.x;
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -523,8 +619,8 @@ __global__ __launch_bounds__(256) void k_mfma_f64(StepArgs a) {
   const int tiles_mn = a.tiles_m * a.tiles_n;
   const int b = t / tiles_mn;
   const int tt = t - b * tiles_mn;
-  const int m0 = (tt / a.tiles_n) * T64;
-  const int n0 = (tt % a.tiles_n) * T64;
+  const int m0 = (tt / a.tiles_n) * TM;
+  const int n0 = (tt % a.tiles_n) * TN;
 
   const double scA = producer_scale<double>(a.partA, a.PA, a.numelA, a.min_norm, r);
   const double scB = producer_scale<double>(a.partB, a.PB, a.numelB, a.min_norm, r);
@@ -533,78 +629,84 @@ __global__ __launch_bounds__(256) void k_mfma_f64(StepArgs a) {
   const double* __restrict__ B = (const double*)tp[a.idB] + a.obB[b];
   double* __restrict__ C = (double*)tp[a.idC] + a.obC[b];
 
-  if (tid < T64) s_omC[tid] = a.omC[m0 + tid];
-  else if (tid < 2 * T64) s_onC[tid - T64] = a.onC[n0 + tid - T64];
+  if (tid < TM) s_omC[tid] = a.omC[m0 + tid];
+  else if (tid < TM + TN) s_onC[tid - TM] = a.onC[n0 + tid - TM];
 
-  // staging: element (free = tid & 63, k = (tid >> 6) + 4 i), i < 4, for both operands
-  const int fr = tid & 63, kr = tid >> 6;
-  const int offa = a.omA[m0 + fr], offb = a.onB[n0 + fr];
-  const bool ina = m0 + fr < a.M, inb = n0 + fr < a.N;
-  double va[4], vb[4];
-  int ka[4], kb[4];
-  auto tab = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { ka[i] = a.okA[k0 + kr + 4 * i]; kb[i] = a.okB[k0 + kr + 4 * i]; }
-  };
-  auto load = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { va[i] = A[offa + ka[i]]; vb[i] = B[offb + kb[i]]; }
-  };
-  auto store = [&](double* dA, double* dB, int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool kin = k0 + kr + 4 * i < a.K;
-      dA[(kr + 4 * i) * LD + fr] = (ina && kin) ? va[i] : 0.0;
-      dB[(kr + 4 * i) * LD + fr] = (inb && kin) ? vb[i] : 0.0;
-    }
-  };
+  LA la;
+  LB lb;
+  la.init(a.omA, m0, a.M, tid);
+  lb.init(a.onB, n0, a.N, tid);
 
   const int lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 32;
   const int l15 = lane & 15, q = lane >> 4;
-  f64x4 acc[2][2];
+  f64x4 acc[4][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
 
   const int nkt = (a.K + BK - 1) / BK;
-  tab(0);
-  load();
-  tab(BK);
-  store(sA, sB, 0);
+  la.tab(a.okA, 0, tid);
+  lb.tab(a.okB, 0, tid);
+  la.load(A);
+  lb.load(B);
+  la.tab(a.okA, BK, tid);
+  lb.tab(a.okB, BK, tid);
+  la.store(sA, 0, a.K, tid);
+  lb.store(sB, 0, a.K, tid);
   __syncthreads();
+
+  const int fa = q * LDA + wm + l15, fb = q * LDB + wn + l15;  // + (4 kk) * LD + 16 * tile
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nkt;
     if (more) {
-      load();
-      tab((kt + 2) * BK);
+      la.load(A);
+      lb.load(B);
+      la.tab(a.okA, (kt + 2) * BK, tid);
+      lb.tab(a.okB, (kt + 2) * BK, tid);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const double* cA = sA + cur * SZ;
-    const double* cB = sB + cur * SZ;
+    const double* cA = sA + cur * SZA;
+    const double* cB = sB + cur * SZB;
+    double xa[2][4], xb[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xa[0][i] = cA[fa + 16 * i];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xb[0][j] = cB[fb + 16 * j];
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      const int k = kk * 4 + q;
-      const double a0 = cA[k * LD + wm + l15], a1 = cA[k * LD + wm + 16 + l15];
-      const double b0 = cB[k * LD + wn + l15], b1 = cB[k * LD + wn + 16 + l15];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      const int c = kk & 1, nx = c ^ 1;
+      if (kk + 1 < BK / 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xa[nx][i] = cA[fa + (kk + 1) * 4 * LDA + 16 * i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xb[nx][j] = cB[fb + (kk + 1) * 4 * LDB + 16 * j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][i], xb[c][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (more) store(sA + (cur ^ 1) * SZ, sB + (cur ^ 1) * SZ, (kt + 1) * BK);
+    if (more) {
+      la.store(sA + (cur ^ 1) * SZA, (kt + 1) * BK, a.K, tid);
+      lb.store(sB + (cur ^ 1) * SZB, (kt + 1) * BK, a.K, tid);
+    }
     __syncthreads();
   }
 
-  // epilogue: operands' rescale factors divide the accumulator (division, as in the reference)
+  // epilogue: lazy rescale (reciprocal multiplies, as in the fp32 kernel), table-driven stores
+  const double iA = 1.0 / scA, iB = 1.0 / scB;
   double asum = 0.0;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = wn + j * 16 + l15;
@@ -614,7 +716,7 @@ __global__ __launch_bounds__(256) void k_mfma_f64(StepArgs a) {
       for (int e = 0; e < 4; ++e) {
         const int row = wm + i * 16 + q + 4 * e;
         if (cin && m0 + row < a.M) {
-          const double v = (acc[i][j][e] / scA) / scB;
+          const double v = (acc[i][j][e] * iA) * iB;
           C[s_omC[row] + offn] = v;
           asum += fabs(v);
         }

@@ -307,7 +307,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + st.tileN - 1) / st.tileN));
     } else if (kEnableMfmaF64 && P.dtype == CTN_F64 && tileable) {
       st.kernel = CTN_KERNEL_MFMA_F64;
-      st.blocks = (int)(st.Bt * ((st.M + kTile64 - 1) / kTile64) * ((st.N + kTile64 - 1) / kTile64));
+      st.blocks = (int)(st.Bt * ((st.M + kTile64M - 1) / kTile64M) * ((st.N + kTile64N - 1) / kTile64N));
     } else if (outs <= kMaxPartials && st.K >= 512) {
       st.kernel = CTN_KERNEL_DOT;
       st.blocks = (int)outs;

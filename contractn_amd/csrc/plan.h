@@ -18,7 +18,8 @@ namespace ctn {
 constexpr int kMaxPartials = 64;   // abs-sum partial slots per (step, replica): one wave reduces them
 constexpr int kTileM = 128;        // MFMA f32 workgroup tile
 constexpr int kTileN = 128;
-constexpr int kTile64 = 64;        // MFMA f64 workgroup tile
+constexpr int kTile64M = 128;      // MFMA f64 workgroup tile: 128 x 64
+constexpr int kTile64N = 64;
 constexpr bool kEnableMfmaF64 = true;
 constexpr int kPadK = 32;          // k-offset tables are padded to this multiple
 constexpr int kStreamMaxBlocks = 4096;  // streaming kernels: grid cap (16 workgroups per CU), threads stride

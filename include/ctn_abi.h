@@ -55,8 +55,9 @@ typedef enum {
   CTN_KERNEL_ELEMENT = 0, /* streaming gather-multiply: one thread per 16-byte output vector, K loop
                              (copy-tensor / hyperedge products, Khatri-Rao, traces, small-K steps) */
   CTN_KERNEL_DOT = 1,     /* one workgroup per output element, K split over lanes */
-  CTN_KERNEL_MFMA_F32 = 2,/* 128x128 LDS-tiled v_mfma_f32_32x32x2_f32 GEMM, gather loads */
-  CTN_KERNEL_MFMA_F64 = 3,/* 64x64 LDS-tiled v_mfma_f64_16x16x4_f64 GEMM, gather loads */
+  CTN_KERNEL_MFMA_F32 = 2,/* 128x128 / 128x64 LDS-tiled v_mfma_f32_32x32x2_f32 GEMM, gather loads;
+                             64x64 split-K form when a launch cannot fill the chip */
+  CTN_KERNEL_MFMA_F64 = 3,/* 128x64 LDS-tiled v_mfma_f64_16x16x4_f64 GEMM, gather loads */
   CTN_KERNEL_ROWDOT = 4   /* one wave per output element, lanes along a unit-stride K (GEMV-like) */
 } ctn_kernel_kind;
 
