@@ -252,3 +252,24 @@ def test_clone_nodes_pack_base_tensor():
     ops = make_arg_packer(tn)(tn.params, ())
     assert len(ops) == 2 and ops[0] is ops[1]
     assert tn.einsum_str == "ab,cb->ac"
+
+
+def test_copy_node_with_two_open_legs_is_rejected_at_contraction():
+    """the einsum string repeats an output symbol; contraction must refuse it."""
+    from contractn_amd import paths
+
+    tn = TN()
+    hub = tn.add_copy_node(3, dim=2)
+    vec = tn.add_dense_node(np.ones(2))
+    tn.connect_nodes(hub, vec, 0, 0)
+    assert tn.einsum_str == "a->aa"
+    with pytest.raises(ValueError, match="repeat"):
+        paths.contraction_list(tn.einsum_str, [(2,)])
+
+
+def test_edge_other_endpoint():
+    tn = TN()
+    a, b = tn.add_dense_node(np.ones((2, 3))), tn.add_dense_node(np.ones((3, 2)))
+    tn.connect_nodes(a, b, 1, 0)
+    e = a[1]
+    assert e.other(a) is b and e.other(b) is a

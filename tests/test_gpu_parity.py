@@ -200,3 +200,20 @@ def test_executor_cache_is_bounded_and_clearable():
     assert len(EE._EXECUTOR_LRU) == 0
     a = rng.standard_normal((5, 4))
     np.testing.assert_allclose(contract("ab,cb->ac", a, a), a @ a.T, rtol=1e-12)
+
+
+def test_clone_nodes_contract_with_shared_weights():
+    """Weight sharing (broken in the reference, works here): a clone node is the
+    same tensor appearing twice in the einsum."""
+    from contractn_amd import TN
+
+    rng = np.random.default_rng(8)
+    w = rng.standard_normal((4, 6))
+    tn = TN()
+    base = tn.add_dense_node(w)
+    clone = tn.add_duplicate_node(base)
+    tn.connect_nodes(base, clone, 1, 1)
+    assert tn.einsum_str == "ab,cb->ac" and len(tn.params) == 1
+    np.testing.assert_allclose(tn.contract(), w @ w.T, rtol=1e-12)
+    t, c = tn.make_contract_fun(split_format=True)((2.0 * w,), ())
+    np.testing.assert_allclose(t * np.exp(c), 4.0 * (w @ w.T), rtol=1e-12)
