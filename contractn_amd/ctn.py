@@ -300,6 +300,35 @@ class TN:
         contract_fun.arg_packer = arg_packer
         return contract_fun
 
+    def make_batched_contract_fun(self, replicas, optimize="auto", dtype=None, device=0):
+        """Throughput form of :meth:`make_contract_fun`: ``fun(params_list, inputs_list)`` contracts
+        ``replicas`` independent parameter sets of this network in ONE launch sequence (every
+        pairwise step is a single kernel over all replicas) and returns ``(t_hat, log_scale)``
+        stacked along a leading replica axis (split format).  A dependent chain of steps cannot
+        fill the GPU with one network; this is how the headline throughput is reached."""
+        import numpy as np
+
+        from .einsum import BatchedContraction
+
+        einstr = self.einsum_str
+        arg_packer = make_arg_packer(self)
+        state = {}
+
+        def batched_contract_fun(params_list, inputs_list=None):
+            assert len(params_list) == replicas
+            inputs_list = inputs_list if inputs_list is not None else [()] * replicas
+            sets = [arg_packer(p, i) for p, i in zip(params_list, inputs_list)]
+            if "bc" not in state:
+                shapes = [tuple(o.shape) for o in sets[0]]
+                dt = dtype or np.result_type(*[np.asarray(o).dtype for o in sets[0]])
+                dt = np.float32 if dt == np.float32 else np.float64
+                state["bc"] = BatchedContraction(einstr, shapes, dt, optimize=optimize, replicas=replicas,
+                                                 device=device)
+            return state["bc"].run_host(sets)
+
+        batched_contract_fun.einsum_str = einstr
+        return batched_contract_fun
+
     def contract(self, inputs=(), optimize="auto", split_format=False):
         """Contract the network to a dense tensor (reference ctn.py:389-409)."""
         fun = self.make_contract_fun(optimize=optimize, split_format=split_format)

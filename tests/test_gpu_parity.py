@@ -217,3 +217,21 @@ def test_clone_nodes_contract_with_shared_weights():
     np.testing.assert_allclose(tn.contract(), w @ w.T, rtol=1e-12)
     t, c = tn.make_contract_fun(split_format=True)((2.0 * w,), ())
     np.testing.assert_allclose(t * np.exp(c), 4.0 * (w @ w.T), rtol=1e-12)
+
+
+def test_tn_level_batched_contract_fun():
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+
+    tn, ssa = nets.mps_overlap(TN, 5, 16, 3, dtype=np.float64, seed=1)
+    path = ssa_to_linear(ssa, 10)
+    single = tn.make_contract_fun(optimize=path, split_format=True)
+    batched = tn.make_batched_contract_fun(4, optimize=path)
+    rng = np.random.default_rng(2)
+    plist = [tuple(p * rng.uniform(0.5, 2.0) for p in tn.params) for _ in range(4)]
+    t, c = batched(plist)
+    assert t.shape == (4,) and c.shape == (4,)
+    for r in range(4):
+        t1, c1 = single(plist[r], ())
+        assert float(t[r]) == float(t1) and float(c[r]) == float(c1)
