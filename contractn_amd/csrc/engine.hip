@@ -28,6 +28,7 @@
 
 #include "kernel_args.h"
 #include "kernels_mfma.h"
+#include "kernels_mfma_g.h"
 #include "kernels_stream.h"
 
 namespace ctn {
@@ -249,13 +250,23 @@ static int exec_launch_all(Exec* E) {
           break;
         }
         a.tiles_n = (int32_t)((st.N + st.tileN - 1) / st.tileN);
-        if (getenv("CTN_DEBUG_STAMPS")) {
+        const char* stamp_step = getenv("CTN_DEBUG_STAMP_STEP");  // stamp only this step's launch
+        if (getenv("CTN_DEBUG_STAMPS") && (!stamp_step || atoi(stamp_step) == s)) {
           if (E->dbg_tiles < (size_t)total) {
             if (E->d_dbg) (void)hipFree(E->d_dbg);
-            HIPCHECK(hipMalloc((void**)&E->d_dbg, (size_t)total * 32));
+            HIPCHECK(hipMalloc((void**)&E->d_dbg, (size_t)total * 64));
             E->dbg_tiles = (size_t)total;
           }
           a.dbg = E->d_dbg;
+        }
+        // large-tile LDS-DMA variant (kernels_mfma_g.h) where the step's shape allows it
+        static const bool use_g = []{ const char* e = getenv("CTN_MFMA_G"); return e && atoi(e) != 0; }();
+        if (use_g && !a.dbg && st.modeA == 1 && st.modeB == 1 && st.tileN == kTileN && a.c_vec && st.M % GM == 0 &&
+            st.N % GN == 0 && st.K % GK == 0 && st.K >= 2 * GK) {
+          a.tiles_m = (int32_t)(st.M / GM);
+          a.blocks_per_replica = (int32_t)(st.blocks / 2);
+          hipLaunchKernelGGL(k_mfma_f32_g, dim3((unsigned)(total / 2)), dim3(256), 0, E->stream, a);
+          break;
         }
         launch_mfma(st.modeA, st.modeB, st.tileN, dim3((unsigned)total), E->stream, a);
         break;
@@ -569,7 +580,7 @@ int ctn_exec_synchronize(ctn_exec* exec) {
   if (const char* path = getenv("CTN_DEBUG_STAMPS")) {  // development only: dump the last MFMA launch's stamps
     Exec* E = &exec->e;
     if (E->d_dbg && E->dbg_tiles) {
-      std::vector<unsigned long long> h(E->dbg_tiles * 4);
+      std::vector<unsigned long long> h(E->dbg_tiles * 8);
       HIPCHECK(hipMemcpy(h.data(), E->d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
       if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }

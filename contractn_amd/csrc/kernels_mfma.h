@@ -2,6 +2,9 @@
 // Part of the gfx950 contraction engine (see engine.hip for the overview).
 #pragma once
 #include "kernel_args.h"
+#ifndef CTN_EXP
+#define CTN_EXP 0
+#endif
 
 namespace ctn {
 
@@ -186,9 +189,22 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLo
     fa[0][0] = cA[fa0]; fa[0][1] = cA[fa1];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) fb[0][j] = cB[fbx[j]];
+#if CTN_EXP == 1 || CTN_EXP == 3
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int c = kk & 1, nx = c ^ 1;
+#if CTN_EXP == 2 || CTN_EXP == 3
+      if (kk == BK / 2 - 2) {  // stage the next tile while the last MFMAs of this one run
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          la.template store<FULL>(sA + (cur ^ 1) * SZA, (kt + 1) * BK, K, tid);
+          lb.template store<FULL>(sB + (cur ^ 1) * SZB, (kt + 1) * BK, K, tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       if (kk + 1 < BK / 2) {
         fa[nx][0] = cA[fa0 + (kk + 1) * stepA]; fa[nx][1] = cA[fa1 + (kk + 1) * stepA];
 #pragma unroll
@@ -204,10 +220,15 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLo
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
     }
     __builtin_amdgcn_sched_barrier(0);  // the staged tile is consumed only after the MFMA phase
+#if CTN_EXP == 1 || CTN_EXP == 3
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#if !(CTN_EXP == 2 || CTN_EXP == 3)
     if (more) {
       la.template store<FULL>(sA + (cur ^ 1) * SZA, (kt + 1) * BK, K, tid);
       lb.template store<FULL>(sB + (cur ^ 1) * SZB, (kt + 1) * BK, K, tid);
     }
+#endif
     __syncthreads();
   }
 }
@@ -243,7 +264,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   const int n0 = (tt % a.tiles_n) * TN;
 
 #ifdef CTN_STAMPS
-  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 0] = __builtin_amdgcn_s_memtime();
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 0] = __builtin_amdgcn_s_memtime();
 #endif
   const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
   const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
@@ -274,7 +295,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
 #ifdef CTN_STAMPS
-  unsigned long long* stamp1 = a.dbg ? a.dbg + (size_t)pid * 4 + 1 : nullptr;
+  unsigned long long* stamp1 = a.dbg ? a.dbg + (size_t)pid * 8 + 1 : nullptr;
 #else
   unsigned long long* stamp1 = nullptr;
 #endif
@@ -283,7 +304,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   if (full) mfma_mainloop<MA, MB, BK, TN, true>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
   else mfma_mainloop<MA, MB, BK, TN, false>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
 #ifdef CTN_STAMPS
-  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 2] = __builtin_amdgcn_s_memtime();
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 2] = __builtin_amdgcn_s_memtime();
 #endif
 
   // epilogue: lazy rescale, store through the C offset tables, abs-sum partial
@@ -334,12 +355,21 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
         }
       }
       __builtin_amdgcn_wave_barrier();
+#ifdef CTN_STAMPS
+      if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 4 + i] = __builtin_amdgcn_s_memtime();
+#endif
     }
   }
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 192) a.dbg[(size_t)pid * 8 + 6] = __builtin_amdgcn_s_memtime();
+  if (a.dbg && tid == 0)
+    a.dbg[(size_t)pid * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                 ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
   const double tot = block_sum((double)asum, red);
   if (tid == 0) a.partC[(size_t)r * a.partC_stride + t] = tot;
 #ifdef CTN_STAMPS
-  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 4 + 3] = __builtin_amdgcn_s_memtime();
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 3] = __builtin_amdgcn_s_memtime();
 #endif
 }
 

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libctn_hip.so")
+# CTN_LIB_PATH: development override (A/B of kernel experiment builds, `make EXP=n`)
+LIB_PATH = os.environ.get("CTN_LIB_PATH") or os.path.join(_HERE, "lib", "libctn_hip.so")
 
 CTN_F32, CTN_F64 = 0, 1
 CTN_MEM_HOST, CTN_MEM_DEVICE = 0, 1
