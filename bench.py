@@ -33,7 +33,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--replicas", type=int, default=192, help="independent networks per step per GPU")
+    ap.add_argument("--replicas", type=int, default=256, help="independent networks per step per GPU")
     ap.add_argument("--sites", type=int, default=100)
     ap.add_argument("--bond", type=int, default=256)
     ap.add_argument("--phys", type=int, default=4)
@@ -165,7 +165,7 @@ def main():
     # ---- roofline of the dominant kernel (per launch, HIP-event durations) ---------------
     by_kernel = {}
     for s, info in enumerate(infos):
-        key = (info["kernel"], info["mode_a"], info["mode_b"])
+        key = (info["kernel"], info["mode_a"], info["mode_b"], info["tile_m"])
         d = by_kernel.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
         d["ms"] += step_ms_last[s]
         d["flops"] += info["flops"] * Rg
@@ -186,7 +186,8 @@ def main():
             traffic = None
     roofline = {
         "bound": "mfma",
-        "kernel": f"k_{KERNEL_NAMES[dom_key[0]]}<modeA={dom_key[1]},modeB={dom_key[2]}>",
+        "kernel": ("k_mfma_f32_g<4,2> (256x128 tiles, LDS-DMA ring)" if dom_key[0] == 2 and dom_key[3] == 256 else
+                   f"k_{KERNEL_NAMES[dom_key[0]]}<modeA={dom_key[1]},modeB={dom_key[2]}>"),
         "achieved": round(achieved, 3),
         "peak": PEAK_F32_MFMA_TFLOPS,
         "unit": "TFLOP/s",

@@ -258,14 +258,24 @@ static int exec_launch_all(Exec* E) {
             E->dbg_tiles = (size_t)total;
           }
           a.dbg = E->d_dbg;
+          HIPCHECK(hipMemsetAsync(E->d_dbg, 0, E->dbg_tiles * 64, E->stream));
         }
-        // large-tile LDS-DMA variant (kernels_mfma_g.h) where the step's shape allows it
-        static const bool use_g = []{ const char* e = getenv("CTN_MFMA_G"); return e && atoi(e) != 0; }();
-        if (use_g && !a.dbg && st.modeA == 1 && st.modeB == 1 && st.tileN == kTileN && a.c_vec && st.M % GM == 0 &&
-            st.N % GN == 0 && st.K % GK == 0 && st.K >= 2 * GK) {
+        // large-tile LDS-DMA variant (kernels_mfma_g.h) where the step's shape allows it.
+        // CTN_MFMA_G: 0 = never, 1 = 256x128 tiles (default), 3 / 4 = the 256x256 experiments
+        static const int use_g = []{ const char* e = getenv("CTN_MFMA_G"); return e ? atoi(e) : 1; }();
+        static_assert(GM == 256 && GN == kTileN && GK == 16, "planner eligibility rule (plan.cpp) assumes these");
+        if (use_g && st.tileM == GM && a.c_vec) {
           a.tiles_m = (int32_t)(st.M / GM);
-          a.blocks_per_replica = (int32_t)(st.blocks / 2);
-          hipLaunchKernelGGL(k_mfma_f32_g, dim3((unsigned)(total / 2)), dim3(256), 0, E->stream, a);
+          if ((use_g == 3 || use_g == 4) && st.N % 256 == 0) {
+            a.tiles_n = (int32_t)(st.N / 256);
+            a.blocks_per_replica = (int32_t)(st.blocks / 4);
+            const dim3 g4((unsigned)(total / 4));
+            if (use_g == 3) hipLaunchKernelGGL((k_mfma_f32_g<8, 2>), g4, dim3(512), 0, E->stream, a);
+            else hipLaunchKernelGGL((k_mfma_f32_g<4, 4>), g4, dim3(256), 0, E->stream, a);
+          } else {
+            a.blocks_per_replica = (int32_t)(st.blocks / 2);
+            hipLaunchKernelGGL((k_mfma_f32_g<4, 2>), dim3((unsigned)(total / 2)), dim3(256), 0, E->stream, a);
+          }
           break;
         }
         launch_mfma(st.modeA, st.modeB, st.tileN, dim3((unsigned)total), E->stream, a);
@@ -463,6 +473,8 @@ int ctn_plan_step_info(const ctn_plan* plan, int step, ctn_step_info* info) {
   info->partials = s.partials; info->blocks = s.blocks;
   info->flops = s.flops;
   info->out_numel = plan->p.tensors[s.out].numel;
+  info->tile_m = s.kernel == CTN_KERNEL_MFMA_F32 ? s.tileM : (s.kernel == CTN_KERNEL_MFMA_F64 ? kTile64M : 0);
+  info->tile_n = s.kernel == CTN_KERNEL_MFMA_F32 ? s.tileN : (s.kernel == CTN_KERNEL_MFMA_F64 ? kTile64N : 0);
   return CTN_OK;
 }
 

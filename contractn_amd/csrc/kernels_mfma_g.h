@@ -36,10 +36,21 @@ __device__ __forceinline__ void glds16(const float* g, float* lds) {
   __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void k_mfma_f32_g(StepArgs a) {
-  // ONE LDS object: [stage 0 A|B][stage 1 A|B][stage 2 A|B][red 4 doubles]
-  __shared__ __attribute__((aligned(16))) float smem[GST * G_STG + 8];
-  double* red = reinterpret_cast<double*>(smem + GST * G_STG);
+// <NW waves, NJ 32-wide column blocks per wave>:
+//   <4, 2>: 256 x 128 tile, wave 128 x 64, 2 workgroups per CU
+//   <8, 2>: 256 x 256 tile, 8 waves as 2 x 4 of 128 x 64, 1 workgroup per CU
+//   <4, 4>: 256 x 256 tile, wave 128 x 128 (256 accumulator registers, one wave per SIMD): 8 LDS
+//           fragment reads per 16 MFMAs and a third less L2 -> LDS traffic per flop
+template <int NW, int NJ>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_f32_g(StepArgs a) {
+  constexpr int WNC = NW / 2;                       // waves along N (2 along M)
+  constexpr int TNB = WNC * 32 * NJ;                // tile columns
+  constexpr int NREQ = 2 * (GK / NW);               // LDS-DMA instructions per wave and k-tile (TNB = 128: 4 + 2)
+  constexpr int SZA = GK * GM, SZB = GK * TNB, STG = SZA + SZB;
+  constexpr int RPW = GK / NW;                      // k-rows of each operand tile loaded by one wave
+  // ONE LDS object: [stage 0 A|B][stage 1 A|B][stage 2 A|B][red NW doubles]
+  __shared__ __attribute__((aligned(16))) float smem[GST * STG + 2 * NW];
+  double* red = reinterpret_cast<double*>(smem + GST * STG);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -47,14 +58,18 @@ __global__ __launch_bounds__(256, 2) void k_mfma_f32_g(StepArgs a) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
   const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  const int r = pid / a.blocks_per_replica;       // here: 256x128 tiles per replica
+  const int r = pid / a.blocks_per_replica;       // here: 256 x TNB tiles per replica
   const int t = pid - r * a.blocks_per_replica;
   const int tiles_mn = a.tiles_m * a.tiles_n;
   const int b = t / tiles_mn;
   const int tt = t - b * tiles_mn;
-  const int m0 = (tt / a.tiles_n) * GM;
-  const int n0 = (tt % a.tiles_n) * GN;
+  const int tm = tt / a.tiles_n, tn = tt % a.tiles_n;
+  const int m0 = tm * GM;
+  const int n0 = tn * TNB;
 
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 0] = __builtin_amdgcn_s_memtime();
+#endif
   const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
   const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
 
@@ -64,70 +79,88 @@ __global__ __launch_bounds__(256, 2) void k_mfma_f32_g(StepArgs a) {
   float* __restrict__ C = (float*)tp[a.idC] + a.obC[b];
 
   const int l31 = lane & 31, h = lane >> 5;
-  const int wm = (w >> 1) * 128, wn = (w & 1) * 64;
+  const int wm = (w / WNC) * 128, wn = (w % WNC) * (32 * NJ);
 
   // epilogue addressing, fetched before any LDS-DMA is in flight
-  int offm[4], offn[2][4];
+  int offm[4], offn[NJ][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) offm[i] = a.omC[m0 + wm + 32 * i + l31];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) offn[j][g] = a.onC[n0 + wn + 32 * j + 8 * g + 4 * h];
 
-  // loader: wave w fills k-rows 4w .. 4w+3 of every stage; A row = 64 lanes x 4 rows of the tile,
-  // B row pair = lanes 0-31 -> k-row, lanes 32-63 -> the next one
+  // loader: wave w fills k-rows RPW*w .. RPW*w + RPW-1 of every stage.  A row = 64 lanes x 4 rows of
+  // the tile; B row (256 wide) likewise, or (128 wide) lanes 0-31 -> k-row, lanes 32-63 -> the next
   const float* __restrict__ Ab = A + a.omA[m0 + 4 * lane];
-  const float* __restrict__ Bb = B + a.onB[n0 + 4 * l31];
-  const_i32_ptr okA = (const_i32_ptr)(a.okA + 4 * w);
-  const_i32_ptr okB = (const_i32_ptr)(a.okB + 4 * w);
+  const float* __restrict__ Bb = B + a.onB[n0 + 4 * (TNB == 128 ? l31 : lane)];
+  const_i32_ptr okA = (const_i32_ptr)(a.okA + RPW * w);
+  const_i32_ptr okB = (const_i32_ptr)(a.okB + RPW * w);
   const int nkt = a.K / GK;
 
-  int ka[4], kb[4];  // k-offset table entries of the next k-tile to request (wave-uniform)
+  int ka[RPW], kb[RPW];  // k-offset table entries of the next k-tile to request (wave-uniform)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { ka[i] = okA[i]; kb[i] = okB[i]; }
+  for (int i = 0; i < RPW; ++i) { ka[i] = okA[i]; kb[i] = okB[i]; }
 
-  auto request = [&](int kt_next, int stage) {  // issue the 6 LDS-DMA loads of one k-tile, then look up the next offsets
-    float* sa = smem + stage * G_STG + (4 * w) * GM;
-    float* sb = smem + stage * G_STG + G_SZA + (4 * w) * GN;
-    glds16(Ab + ka[0], sa);
-    glds16(Ab + ka[1], sa + GM);
-    glds16(Ab + ka[2], sa + 2 * GM);
-    glds16(Ab + ka[3], sa + 3 * GM);
-    glds16(Bb + (h ? kb[1] : kb[0]), sb);
-    glds16(Bb + (h ? kb[3] : kb[2]), sb + 2 * GN);
+  auto request = [&](int kt_next, int stage) {  // issue this wave's LDS-DMA loads of one k-tile, then look up the next offsets
+    float* sa = smem + stage * STG + (RPW * w) * GM;
+    float* sb = smem + stage * STG + SZA + (RPW * w) * TNB;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) glds16(Ab + ka[i], sa + i * GM);
+    if (TNB == 128) {
+      glds16(Bb + (h ? kb[1] : kb[0]), sb);
+      glds16(Bb + (h ? kb[3] : kb[2]), sb + 2 * TNB);
+    } else {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) glds16(Bb + kb[i], sb + i * TNB);
+    }
     const int k0 = kt_next * GK;  // the tables are padded by 64 entries past K
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ka[i] = okA[k0 + i]; kb[i] = okB[k0 + i]; }
+    for (int i = 0; i < RPW; ++i) { ka[i] = okA[k0 + i]; kb[i] = okB[k0 + i]; }
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   request(1, 0);
   request(2, 1);                                   // nkt >= 2 is guaranteed by the launcher
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // k-tile 0 has landed (this wave's share)
+  // k-tile 0 has landed (this wave's share): all but the youngest request group
+  if (TNB == 128) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (NREQ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // ... and everybody else's
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 1] = __builtin_amdgcn_s_memtime();
+#endif
 
+  // Main loop.  The barrier of a k-tile sits in the MIDDLE of its MFMA phase, between k-steps whose
+  // fragments are already in registers: by then this wave's requests for the next k-tile (issued a
+  // whole tile earlier) have landed, the barrier publishes them, and the requests for the k-tile
+  // after that follow it (every wave has left the previous k-tile, so its ring stage is free).  The
+  // fragment read-ahead therefore runs straight across the k-tile boundary and a wave never waits
+  // on LDS or on its peers with an empty matrix pipe.
   const int fa0 = h * GM + wm + l31;
-  const int fb0 = h * GN + wn + l31;
-  int st_cur = 0, st_req = 2;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const bool ahead = kt + 2 < nkt;
-    if (ahead) request(kt + 3, st_req);
-    __builtin_amdgcn_sched_barrier(0);
-    const float* cA = smem + st_cur * G_STG + fa0;
-    const float* cB = smem + st_cur * G_STG + G_SZA + fb0;
-    float fa[2][4], fb[2][2];
+  const int fb0 = h * TNB + wn + l31;
+  int st_cur = 0, st_nxt = 1, st_req = 2;
+  float fa[2][4], fb[2][NJ];
+  {
+    const float* cA = smem + fa0;
+    const float* cB = smem + SZA + fb0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[0][i] = cA[32 * i];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[0][j] = cB[32 * j];
+    for (int j = 0; j < NJ; ++j) fb[0][j] = cB[32 * j];
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    const float* cA = smem + st_cur * STG + fa0;
+    const float* cB = smem + st_cur * STG + SZA + fb0;
+    const float* nA = smem + st_nxt * STG + fa0;
+    const float* nB = smem + st_nxt * STG + SZA + fb0;
 #pragma unroll
     for (int kk = 0; kk < GK / 2; ++kk) {
       const int c = kk & 1, nx = c ^ 1;
@@ -135,25 +168,36 @@ __global__ __launch_bounds__(256, 2) void k_mfma_f32_g(StepArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[nx][i] = cA[(kk + 1) * 2 * GM + 32 * i];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[nx][j] = cB[(kk + 1) * 2 * GN + 32 * j];
+        for (int j = 0; j < NJ; ++j) fb[nx][j] = cB[(kk + 1) * 2 * TNB + 32 * j];
+      } else if (kt + 1 < nkt) {  // first k-step of the next k-tile (published by this tile's barrier)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[nx][i] = nA[32 * i];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[nx][j] = nB[32 * j];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c][j], fa[c][i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+      if (kk == GK / 4 - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // k-tile kt+1: this wave's requests, a tile old
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) request(kt + 3, st_req);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // retire k-tile kt+1 (all but the 6 youngest = k-tile kt+2's requests), then meet the others
-    if (ahead) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    st_cur = st_cur == GST - 1 ? 0 : st_cur + 1;
+    st_cur = st_nxt;
+    st_nxt = st_req;
     st_req = st_req == GST - 1 ? 0 : st_req + 1;
   }
 
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 2] = __builtin_amdgcn_s_memtime();
+#endif
   // epilogue: lazy rescale, 16-byte stores straight from the accumulators, abs-sum partial
   const float iA = 1.0f / scA, iB = 1.0f / scB;
   float asum = 0.f;
@@ -161,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_f32_g(StepArgs a) {
   for (int i = 0; i < 4; ++i) {
     float* __restrict__ row = C + offm[i];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float4 v;
@@ -173,10 +217,27 @@ __global__ __launch_bounds__(256, 2) void k_mfma_f32_g(StepArgs a) {
         asum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
       }
   }
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 0) {
+    a.dbg[(size_t)pid * 8 + 4] = __builtin_amdgcn_s_memtime();
+    a.dbg[(size_t)pid * 8 + 5] = a.dbg[(size_t)pid * 8 + 4];
+    a.dbg[(size_t)pid * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                 ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
+  if (a.dbg && tid == 192) a.dbg[(size_t)pid * 8 + 6] = __builtin_amdgcn_s_memtime();
+#endif
   const double tot = block_sum((double)asum, red);
-  if (tid == 0) {  // this tile covers two of the planner's 128-row partial slots
-    a.partC[(size_t)r * a.partC_stride + 2 * t] = tot;
-    a.partC[(size_t)r * a.partC_stride + 2 * t + 1] = 0.0;
+#ifdef CTN_STAMPS
+  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 3] = __builtin_amdgcn_s_memtime();
+#endif
+  if (tid == 0) {  // this tile covers 2 x (TNB / 128) of the planner's 128 x 128 partial slots
+    double* pc = a.partC + (size_t)r * a.partC_stride + (size_t)b * (2 * (TNB / 128)) * tiles_mn;
+    const int tn128 = a.tiles_n * (TNB / 128);
+#pragma unroll
+    for (int dm = 0; dm < 2; ++dm)
+#pragma unroll
+      for (int dn = 0; dn < TNB / 128; ++dn)
+        pc[(2 * tm + dm) * tn128 + (TNB / 128) * tn + dn] = (dm == 0 && dn == 0) ? tot : 0.0;
   }
 }
 

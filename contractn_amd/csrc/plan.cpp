@@ -305,6 +305,11 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       // 64-wide column tiles when they cover N with less padding (e.g. N = 64, 192, 320)
       st.tileN = ((st.N + 63) / 64) * 64 < ((st.N + kTileN - 1) / kTileN) * kTileN ? 64 : kTileN;
       st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + st.tileN - 1) / st.tileN));
+      // 256 x 128 tiles fed by LDS-DMA where every tile is full and both operands are unit-stride along
+      // their free index (blocks / partial slots stay counted in 128 x 128 units)
+      if (st.modeA == 1 && st.modeB == 1 && st.tileN == kTileN && st.cvec && st.M % 256 == 0 && st.N % kTileN == 0 &&
+          st.K % 16 == 0 && st.K >= 32)
+        st.tileM = 256;
     } else if (kEnableMfmaF64 && P.dtype == CTN_F64 && tileable) {
       st.kernel = CTN_KERNEL_MFMA_F64;
       st.blocks = (int)(st.Bt * ((st.M + kTile64M - 1) / kTile64M) * ((st.N + kTile64N - 1) / kTile64N));

@@ -57,6 +57,7 @@ struct Step {
   int vecw = 1;          // output elements per thread (16-byte vectors when > 1)
   bool chain_ok = false; // small enough for the persistent chain walker
   int tileN = kTileN;    // MFMA f32 column tile: 128, or 64 when that wastes less padding
+  int tileM = kTileM;    // MFMA f32 row tile: 128, or 256 = the large-tile LDS-DMA kernel (kernels_mfma_g.h)
   bool cvec = false;   // 16-byte vector stores of C are valid (unit-stride column label, aligned strides)
   int blocks = 1;      // workgroups per replica
   int partials = 1;    // partial abs-sums per replica after the optional collapse pass

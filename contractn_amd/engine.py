@@ -71,6 +71,8 @@ class StepInfo(C.Structure):
         ("blocks", C.c_int32),
         ("flops", C.c_double),
         ("out_numel", C.c_int64),
+        ("tile_m", C.c_int32),
+        ("tile_n", C.c_int32),
     ]
 
 

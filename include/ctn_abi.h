@@ -56,6 +56,7 @@ typedef enum {
                              (copy-tensor / hyperedge products, Khatri-Rao, traces, small-K steps) */
   CTN_KERNEL_DOT = 1,     /* one workgroup per output element, K split over lanes */
   CTN_KERNEL_MFMA_F32 = 2,/* 128x128 / 128x64 LDS-tiled v_mfma_f32_32x32x2_f32 GEMM, gather loads;
+                             256x128 tiles fed by LDS-DMA when every tile is full (tile_m = 256);
                              64x64 split-K form when a launch cannot fill the chip */
   CTN_KERNEL_MFMA_F64 = 3,/* 128x64 LDS-tiled v_mfma_f64_16x16x4_f64 GEMM, gather loads */
   CTN_KERNEL_ROWDOT = 4   /* one wave per output element, lanes along a unit-stride K (GEMV-like) */
@@ -96,6 +97,8 @@ typedef struct {
   int32_t blocks;      /* workgroups per replica */
   double flops;        /* 2*|B||M||N||K| (|B||M||N| when K is empty) + 3*numel(out) */
   int64_t out_numel;
+  int32_t tile_m;      /* MFMA steps: workgroup tile rows (fp32: 128, or 256 = LDS-DMA large-tile kernel); else 0 */
+  int32_t tile_n;      /* MFMA steps: workgroup tile columns (fp32: 128 / 64, fp64: 64); else 0 */
 } ctn_step_info;
 
 /* ---- library ---------------------------------------------------------- */

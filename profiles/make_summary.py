@@ -18,7 +18,7 @@ import sys
 
 def find(d, suffix):
     hits = glob.glob(os.path.join(d, "*", "*" + suffix))
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None  # scratch dirs keep earlier runs: newest wins
 
 
 def counters(path):

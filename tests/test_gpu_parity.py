@@ -235,3 +235,52 @@ def test_tn_level_batched_contract_fun():
     for r in range(4):
         t1, c1 = single(plist[r], ())
         assert float(t[r]) == float(t1) and float(c[r]) == float(c1)
+
+
+# --- the large-tile LDS-DMA MFMA kernel (k_mfma_f32_g): steps with both operands unit-stride along
+# their free index, M % 256 == 0, N % 128 == 0, K % 16 == 0, K >= 32 --------------------------------
+def _g_eligible(info):
+    return (info["kernel"] == 2 and info["mode_a"] == 1 and info["mode_b"] == 1 and info["m"] % 256 == 0
+            and info["n"] % 128 == 0 and info["k"] % 16 == 0 and info["k"] >= 32)
+
+
+@pytest.mark.parametrize("einstr,shapes,path", [
+    ("km,kn->mn", [(32, 256), (32, 128)], None),                    # one tile, two k-tiles (ring minimum)
+    ("km,kn->mn", [(48, 512), (48, 384)], None),                    # 2 x 3 tiles, three k-tiles
+    ("km,kn->mn", [(272, 256), (272, 256)], None),                  # 17 k-tiles: ring wraps many times
+    ("xkm,xkn->xmn", [(3, 64, 256), (3, 64, 128)], None),           # batch (hyperedge) label
+    ("kam,kbn->ambn", [(64, 2, 128), (64, 2, 64)], None),           # composite free indices, strided C rows
+    ("km,kn,nj->mj", [(64, 256), (64, 256), (256, 256)], ((0, 1), (0, 1))),  # an operand = rescaled intermediate
+])
+def test_large_tile_dma_kernel_vs_numpy(einstr, shapes, path):
+    rng = np.random.default_rng(7)
+    ops = [(rng.standard_normal(s) * rng.uniform(0.5, 3.0)).astype(np.float32) for s in shapes]
+    kw = {"optimize": path} if path is not None else {}
+    clist = E._contract_path(einstr, tuple(shapes), optimize=path if path is not None else "auto",
+                             memory_limit=None, use_blas=True)
+    infos = E._native_plan(clist, tuple(shapes), "float32").step_infos()
+    assert _g_eligible(infos[-1]), infos[-1]       # keeps this test on the kernel it is about
+    t_hat, c = contract(einstr, *ops, split_format=True, **kw)
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    got = t_hat.astype(np.float64) * np.exp(float(c))
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 2e-5 * np.max(np.abs(ref)) * 10
+    assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-5
+
+
+def test_large_tile_dma_kernel_replicas_and_exact_sums():
+    # small integers: every product and partial sum is exact in fp32, so the result must be bit-identical
+    # to NumPy and identical across replicas holding the same data
+    rng = np.random.default_rng(11)
+    A = rng.integers(-3, 4, size=(96, 256)).astype(np.float32)
+    B = rng.integers(-3, 4, size=(96, 256)).astype(np.float32)
+    bc = E.BatchedContraction("km,kn->mn", [A.shape, B.shape], np.float32, optimize=((0, 1),), replicas=3)
+    assert _g_eligible(bc.plan.step_infos()[0])
+    t, c = bc.run_host([[A, B], [2 * A, B], [A, B]])
+    ref = A.T.astype(np.float64) @ B.astype(np.float64)
+    for r, f in enumerate((1.0, 2.0, 1.0)):
+        got = t[r].astype(np.float64) * np.exp(float(c[r]))
+        assert np.max(np.abs(got - f * ref)) <= 1e-5 * np.max(np.abs(ref))
+    assert np.array_equal(t[0], t[2]) and float(c[0]) == float(c[2])
+    norm = np.abs(ref).sum()
+    assert np.allclose(t[0].astype(np.float64), ref / (norm / ref.size), rtol=3e-7, atol=0)
