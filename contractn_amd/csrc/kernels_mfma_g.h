@@ -94,6 +94,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   // the tile; B row (256 wide) likewise, or (128 wide) lanes 0-31 -> k-row, lanes 32-63 -> the next
   const float* __restrict__ Ab = A + a.omA[m0 + 4 * lane];
   const float* __restrict__ Bb = B + a.onB[n0 + 4 * (TNB == 128 ? l31 : lane)];
+  // k-offset table entries: scalar loads through the constant address space (measured: fetching them
+  // with wave-uniform vector loads next to the LDS-DMA requests costs 2.5 % on the headline)
   const_i32_ptr okA = (const_i32_ptr)(a.okA + RPW * w);
   const_i32_ptr okB = (const_i32_ptr)(a.okB + RPW * w);
   const int nkt = a.K / GK;
@@ -130,9 +132,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   request(1, 0);
   request(2, 1);                                   // nkt >= 2 is guaranteed by the launcher
   // k-tile 0 has landed (this wave's share): all but the youngest request group
-  if (TNB == 128) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (NREQ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if (TNB == 128) __builtin_amdgcn_s_waitcnt(0xF76) /* vmcnt(6) */;
+  else if (NREQ == 4) __builtin_amdgcn_s_waitcnt(0xF74) /* vmcnt(4) */;
+  else __builtin_amdgcn_s_waitcnt(0xF78) /* vmcnt(8) */;
   __builtin_amdgcn_s_barrier();                    // ... and everybody else's
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 1] = __builtin_amdgcn_s_memtime();
@@ -180,11 +182,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c][j], fa[c][i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4 + NJ, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+      // issue order: the first MFMA of the step (its operand wait then only covers reads that are a
+      // whole k-step old), the fragment reads of the next step (pairs merge into ds_read2_b32), the rest
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, (4 + NJ) / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 1, 0);
       if (kk == GK / 4 - 1) {
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // k-tile kt+1: this wave's requests, a tile old
+        __builtin_amdgcn_s_waitcnt(0xF70) /* vmcnt(0) */;  // k-tile kt+1: this wave's requests, a tile old
         __builtin_amdgcn_s_barrier();
         if (kt + 2 < nkt) request(kt + 3, st_req);
         __builtin_amdgcn_sched_barrier(0);
