@@ -265,16 +265,17 @@ static int exec_launch_all(Exec* E) {
         static const int use_g = []{ const char* e = getenv("CTN_MFMA_G"); return e ? atoi(e) : 1; }();
         static_assert(GM == 256 && GN == kTileN && GK == 16, "planner eligibility rule (plan.cpp) assumes these");
         if (use_g && st.tileM == GM && a.c_vec) {
-          a.tiles_m = (int32_t)(st.M / GM);
-          if ((use_g == 3 || use_g == 4) && st.N % 256 == 0) {
+          a.tiles_m = (int32_t)((st.M + GM - 1) / GM);
+          if ((use_g == 3 || use_g == 4) && st.M % 256 == 0 && st.N % 256 == 0) {
             a.tiles_n = (int32_t)(st.N / 256);
-            a.blocks_per_replica = (int32_t)(st.blocks / 4);
-            const dim3 g4((unsigned)(total / 4));
+            a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
+            const dim3 g4((unsigned)((int64_t)a.blocks_per_replica * R));
             if (use_g == 3) hipLaunchKernelGGL((k_mfma_f32_g<8, 2>), g4, dim3(512), 0, E->stream, a);
             else hipLaunchKernelGGL((k_mfma_f32_g<4, 4>), g4, dim3(256), 0, E->stream, a);
           } else {
-            a.blocks_per_replica = (int32_t)(st.blocks / 2);
-            hipLaunchKernelGGL((k_mfma_f32_g<4, 2>), dim3((unsigned)(total / 2)), dim3(256), 0, E->stream, a);
+            a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
+            hipLaunchKernelGGL((k_mfma_f32_g<4, 2>), dim3((unsigned)((int64_t)a.blocks_per_replica * R)), dim3(256), 0,
+                               E->stream, a);
           }
           break;
         }

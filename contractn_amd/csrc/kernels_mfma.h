@@ -189,22 +189,9 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLo
     fa[0][0] = cA[fa0]; fa[0][1] = cA[fa1];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) fb[0][j] = cB[fbx[j]];
-#if CTN_EXP == 1 || CTN_EXP == 3
-    __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int c = kk & 1, nx = c ^ 1;
-#if CTN_EXP == 2 || CTN_EXP == 3
-      if (kk == BK / 2 - 2) {  // stage the next tile while the last MFMAs of this one run
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-          la.template store<FULL>(sA + (cur ^ 1) * SZA, (kt + 1) * BK, K, tid);
-          lb.template store<FULL>(sB + (cur ^ 1) * SZB, (kt + 1) * BK, K, tid);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
       if (kk + 1 < BK / 2) {
         fa[nx][0] = cA[fa0 + (kk + 1) * stepA]; fa[nx][1] = cA[fa1 + (kk + 1) * stepA];
 #pragma unroll
@@ -220,15 +207,10 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLo
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
     }
     __builtin_amdgcn_sched_barrier(0);  // the staged tile is consumed only after the MFMA phase
-#if CTN_EXP == 1 || CTN_EXP == 3
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#if !(CTN_EXP == 2 || CTN_EXP == 3)
     if (more) {
       la.template store<FULL>(sA + (cur ^ 1) * SZA, (kt + 1) * BK, K, tid);
       lb.template store<FULL>(sB + (cur ^ 1) * SZB, (kt + 1) * BK, K, tid);
     }
-#endif
     __syncthreads();
   }
 }

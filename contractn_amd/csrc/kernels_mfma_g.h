@@ -1,6 +1,8 @@
 // kernels_mfma_g.h - fp32 MFMA GEMM, large-tile variant fed by direct-to-LDS loads (LDS-DMA)
 // Part of the gfx950 contraction engine (see engine.hip for the overview).
 #pragma once
+#include <type_traits>
+
 #include "kernels_mfma.h"
 
 namespace ctn {
@@ -12,9 +14,10 @@ namespace ctn {
 // pass) into a 3-stage ring, two k-tiles ahead of the MFMAs; the only synchronisation per k-tile
 // is one counted s_waitcnt vmcnt + one raw s_barrier (a __syncthreads() would drain the ring).
 //
-// Eligibility (checked by the launcher): both operands "mode 1" (unit stride along their free
-// index, so 16 bytes per lane are 4 consecutive rows/columns and a wave instruction fills one
-// lane-linear k-row of the LDS image), M % 256 == 0, N % 128 == 0, K % 16 == 0, K >= 32, C
+// Eligibility (decided by the planner, plan.cpp): both operands "mode 1" (unit stride along their
+// free index, so 16 bytes per lane are 4 consecutive rows/columns and a wave instruction fills one
+// lane-linear k-row of the LDS image), K % 16 == 0 (LDS-DMA cannot mask; ragged M / N only produce
+// rows and columns that the epilogue drops - padded tables keep their loads in bounds), K >= 32, C
 // vector-storable.  Everything else stays on k_mfma_f32.
 //
 // The MFMA is issued with the operands swapped (B fragment as SrcA), i.e. it accumulates C^T
@@ -203,25 +206,35 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 2] = __builtin_amdgcn_s_memtime();
 #endif
-  // epilogue: lazy rescale, 16-byte stores straight from the accumulators, abs-sum partial
+  // epilogue: lazy rescale, 16-byte stores straight from the accumulators, abs-sum partial.
+  // Ragged tiles (M % 256, N % 128) mask whole 16-byte vectors: N % 4 == 0 whenever C is vector-storable.
   const float iA = 1.0f / scA, iB = 1.0f / scB;
   float asum = 0.f;
+  const bool full = (m0 + GM <= a.M) && (n0 + TNB <= a.N);
+  auto store_tile = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float* __restrict__ row = C + offm[i];
+    for (int i = 0; i < 4; ++i) {
+      float* __restrict__ row = C + offm[i];
+      const bool rin = FULL || (m0 + wm + 32 * i + l31 < a.M);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 v;
-        v.x = (acc[i][j][4 * g + 0] * iA) * iB;
-        v.y = (acc[i][j][4 * g + 1] * iA) * iB;
-        v.z = (acc[i][j][4 * g + 2] * iA) * iB;
-        v.w = (acc[i][j][4 * g + 3] * iA) * iB;
-        *reinterpret_cast<float4*>(row + offn[j][g]) = v;
-        asum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
-      }
-  }
+        for (int g = 0; g < 4; ++g) {
+          float4 v;
+          v.x = (acc[i][j][4 * g + 0] * iA) * iB;
+          v.y = (acc[i][j][4 * g + 1] * iA) * iB;
+          v.z = (acc[i][j][4 * g + 2] * iA) * iB;
+          v.w = (acc[i][j][4 * g + 3] * iA) * iB;
+          if (FULL || (rin && n0 + wn + 32 * j + 8 * g + 4 * h < a.N)) {
+            *reinterpret_cast<float4*>(row + offn[j][g]) = v;
+            asum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+          }
+        }
+    }
+  };
+  if (full) store_tile(std::true_type{});
+  else store_tile(std::false_type{});
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) {
     a.dbg[(size_t)pid * 8 + 4] = __builtin_amdgcn_s_memtime();
@@ -235,14 +248,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 3] = __builtin_amdgcn_s_memtime();
 #endif
-  if (tid == 0) {  // this tile covers 2 x (TNB / 128) of the planner's 128 x 128 partial slots
-    double* pc = a.partC + (size_t)r * a.partC_stride + (size_t)b * (2 * (TNB / 128)) * tiles_mn;
-    const int tn128 = a.tiles_n * (TNB / 128);
+  if (tid == 0) {  // this tile covers up to 2 x (TNB / 128) of the planner's 128 x 128 partial slots
+    const int tm128 = (a.M + 127) / 128, tn128 = (a.N + 127) / 128;
+    double* pc = a.partC + (size_t)r * a.partC_stride + (size_t)b * tm128 * tn128;
 #pragma unroll
     for (int dm = 0; dm < 2; ++dm)
 #pragma unroll
-      for (int dn = 0; dn < TNB / 128; ++dn)
-        pc[(2 * tm + dm) * tn128 + (TNB / 128) * tn + dn] = (dm == 0 && dn == 0) ? tot : 0.0;
+      for (int dn = 0; dn < TNB / 128; ++dn) {
+        const int sm = 2 * tm + dm, sn = (TNB / 128) * tn + dn;
+        if (sm < tm128 && sn < tn128) pc[sm * tn128 + sn] = (dm == 0 && dn == 0) ? tot : 0.0;
+      }
   }
 }
 

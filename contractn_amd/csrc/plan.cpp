@@ -305,10 +305,14 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       // 64-wide column tiles when they cover N with less padding (e.g. N = 64, 192, 320)
       st.tileN = ((st.N + 63) / 64) * 64 < ((st.N + kTileN - 1) / kTileN) * kTileN ? 64 : kTileN;
       st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + st.tileN - 1) / st.tileN));
-      // 256 x 128 tiles fed by LDS-DMA where every tile is full and both operands are unit-stride along
-      // their free index (blocks / partial slots stay counted in 128 x 128 units)
-      if (st.modeA == 1 && st.modeB == 1 && st.tileN == kTileN && st.cvec && st.M % 256 == 0 && st.N % kTileN == 0 &&
-          st.K % 16 == 0 && st.K >= 32)
+      // 256 x 128 tiles fed by LDS-DMA (kernels_mfma_g.h): both operands unit-stride along their free
+      // index, K a multiple of the 16-deep k-tile (LDS-DMA cannot mask), and M, N such that 256-row
+      // tiles pad at most 15 % more than 128-row ones (ragged edges are masked in the epilogue).
+      // blocks / partial slots stay counted in 128 x 128 units.
+      const int64_t pad128 = round_up(st.M, kTileM) * round_up(st.N, kTileN);
+      const int64_t pad256 = round_up(st.M, 256) * round_up(st.N, kTileN);
+      if (st.modeA == 1 && st.modeB == 1 && st.tileN == kTileN && st.cvec && st.K % 16 == 0 && st.K >= 32 &&
+          st.M > kTileM && pad256 * 100 <= pad128 * 115)
         st.tileM = 256;
     } else if (kEnableMfmaF64 && P.dtype == CTN_F64 && tileable) {
       st.kernel = CTN_KERNEL_MFMA_F64;
@@ -381,7 +385,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     // -- gather-offset tables
     std::vector<const LabelInfo*> gb(G[kBatch].begin(), G[kBatch].end()), gm(G[kM].begin(), G[kM].end()),
         gn(G[kN].begin(), G[kN].end()), gk(G[kK].begin(), G[kK].end());
-    const int64_t padM = round_up(st.M, kTileM), padN = round_up(st.N, kTileN), padK = round_up(st.K, kPadK) + 2 * kPadK;  // kernels prefetch table entries two tiles ahead
+    const int64_t padM = round_up(st.M, std::max(kTileM, st.tileM)), padN = round_up(st.N, kTileN), padK = round_up(st.K, kPadK) + 2 * kPadK;  // kernels prefetch table entries two tiles ahead
     std::vector<int32_t> tb;
     const bool tiled = st.kernel == CTN_KERNEL_MFMA_F32 || st.kernel == CTN_KERNEL_MFMA_F64 || st.kernel == CTN_KERNEL_DOT;
     if (tiled || st.chain_ok) {  // (batch, m, n) tables: tile kernels and the chain walker

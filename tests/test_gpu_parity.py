@@ -240,8 +240,7 @@ def test_tn_level_batched_contract_fun():
 # --- the large-tile LDS-DMA MFMA kernel (k_mfma_f32_g): steps with both operands unit-stride along
 # their free index, M % 256 == 0, N % 128 == 0, K % 16 == 0, K >= 32 --------------------------------
 def _g_eligible(info):
-    return (info["kernel"] == 2 and info["mode_a"] == 1 and info["mode_b"] == 1 and info["m"] % 256 == 0
-            and info["n"] % 128 == 0 and info["k"] % 16 == 0 and info["k"] >= 32)
+    return info["kernel"] == 2 and info["tile_m"] == 256   # the planner's decision (plan.cpp)
 
 
 @pytest.mark.parametrize("einstr,shapes,path", [
@@ -251,6 +250,9 @@ def _g_eligible(info):
     ("xkm,xkn->xmn", [(3, 64, 256), (3, 64, 128)], None),           # batch (hyperedge) label
     ("kam,kbn->ambn", [(64, 2, 128), (64, 2, 64)], None),           # composite free indices, strided C rows
     ("km,kn,nj->mj", [(64, 256), (64, 256), (256, 256)], ((0, 1), (0, 1))),  # an operand = rescaled intermediate
+    ("km,kn->mn", [(48, 400), (48, 200)], None),                    # ragged M and N: masked edge tiles
+    ("km,kn->mn", [(32, 896), (32, 196)], None),                    # 3.5 row tiles, ragged columns
+    ("xkm,xkn->xmn", [(2, 64, 508), (2, 64, 128)], None),           # batch + 4 masked rows
 ])
 def test_large_tile_dma_kernel_vs_numpy(einstr, shapes, path):
     rng = np.random.default_rng(7)
