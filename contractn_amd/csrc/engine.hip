@@ -55,6 +55,7 @@ struct Exec {
   int R = 1;
   int n_tensors = 0;
   int n_cu = 256;
+  int mfma_g = 1;        // CTN_MFMA_G at creation time (see exec_launch_all)
   char* d_ws = nullptr;
   int32_t* d_tables = nullptr;
   void** d_ptrs = nullptr;
@@ -261,10 +262,14 @@ static int exec_launch_all(Exec* E) {
           HIPCHECK(hipMemsetAsync(E->d_dbg, 0, E->dbg_tiles * 64, E->stream));
         }
         // large-tile LDS-DMA variant (kernels_mfma_g.h) where the step's shape allows it.
-        // CTN_MFMA_G: 0 = never, 1 = 256x128 tiles (default), 3 / 4 = the 256x256 experiments
-        static const int use_g = []{ const char* e = getenv("CTN_MFMA_G"); return e ? atoi(e) : 1; }();
+        // CTN_MFMA_G (read when the executor is created): 0 = never, 1 = 256x128 tiles when the launch
+        // fills the chip (default), 2 = whenever eligible (tests), 3 / 4 = the 256x256 experiments
+        const int use_g = E->mfma_g;
         static_assert(GM == 256 && GN == kTileN && GK == 16, "planner eligibility rule (plan.cpp) assumes these");
-        if (use_g && st.tileM == GM && a.c_vec) {
+        // ... and the launch has at least two of the big tiles per CU: with fewer, 128-row tiles spread the
+        // same work over more CUs (measured: 2048^3 runs at 90 vs 56 TFLOP/s, 4096^3 at 125 vs 135)
+        const int64_t gtiles = st.Bt * ((st.M + GM - 1) / GM) * a.tiles_n * R;
+        if (use_g && st.tileM == GM && a.c_vec && (use_g >= 2 || gtiles >= 2LL * E->n_cu)) {
           a.tiles_m = (int32_t)((st.M + GM - 1) / GM);
           if ((use_g == 3 || use_g == 4) && st.M % 256 == 0 && st.N % 256 == 0) {
             a.tiles_n = (int32_t)(st.N / 256);
@@ -493,7 +498,8 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   if (!x) { g_err = "out of host memory"; return CTN_OOM; }
   Exec& E = x->e;
   const Plan& P = plan->p;
-  E.plan = &P; E.device = device; E.R = replicas; E.n_cu = n_cu > 0 ? n_cu : 256; E.n_cu = n_cu > 0 ? n_cu : 256;
+  E.plan = &P; E.device = device; E.R = replicas; E.n_cu = n_cu > 0 ? n_cu : 256;
+  if (const char* g = getenv("CTN_MFMA_G")) E.mfma_g = atoi(g);
   E.n_tensors = P.n_inputs + P.n_steps + 1;
   auto fail = [&](int code) { delete x; return code; };
 #define HIPCHECK_X(expr)                                                        \

@@ -243,6 +243,16 @@ def _g_eligible(info):
     return info["kernel"] == 2 and info["tile_m"] == 256   # the planner's decision (plan.cpp)
 
 
+@pytest.fixture
+def force_large_tiles(monkeypatch):
+    """By default the launcher keeps small launches (< 2 big tiles per CU) on 128-row tiles; these tests
+    are about the large-tile kernel, so executors created inside them take it whenever a step is eligible."""
+    monkeypatch.setenv("CTN_MFMA_G", "2")
+    E.clear_caches()
+    yield
+    E.clear_caches()
+
+
 @pytest.mark.parametrize("einstr,shapes,path", [
     ("km,kn->mn", [(32, 256), (32, 128)], None),                    # one tile, two k-tiles (ring minimum)
     ("km,kn->mn", [(48, 512), (48, 384)], None),                    # 2 x 3 tiles, three k-tiles
@@ -254,7 +264,7 @@ def _g_eligible(info):
     ("km,kn->mn", [(32, 896), (32, 196)], None),                    # 3.5 row tiles, ragged columns
     ("xkm,xkn->xmn", [(2, 64, 508), (2, 64, 128)], None),           # batch + 4 masked rows
 ])
-def test_large_tile_dma_kernel_vs_numpy(einstr, shapes, path):
+def test_large_tile_dma_kernel_vs_numpy(einstr, shapes, path, force_large_tiles):
     rng = np.random.default_rng(7)
     ops = [(rng.standard_normal(s) * rng.uniform(0.5, 3.0)).astype(np.float32) for s in shapes]
     kw = {"optimize": path} if path is not None else {}
@@ -270,7 +280,7 @@ def test_large_tile_dma_kernel_vs_numpy(einstr, shapes, path):
     assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-5
 
 
-def test_large_tile_dma_kernel_replicas_and_exact_sums():
+def test_large_tile_dma_kernel_replicas_and_exact_sums(force_large_tiles):
     # small integers: every product and partial sum is exact in fp32, so the result must be bit-identical
     # to NumPy and identical across replicas holding the same data
     rng = np.random.default_rng(11)
