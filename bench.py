@@ -33,7 +33,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--replicas", type=int, default=256, help="independent networks per step per GPU")
+    ap.add_argument("--replicas", type=int, default=512, help="independent networks per step per GPU")
     ap.add_argument("--sites", type=int, default=100)
     ap.add_argument("--bond", type=int, default=256)
     ap.add_argument("--phys", type=int, default=4)

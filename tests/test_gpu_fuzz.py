@@ -84,3 +84,45 @@ def test_random_pairwise_step_f32_larger(seed):
     got = np.asarray(t_hat, dtype=np.float64) * np.exp(float(c))
     scale = max(np.max(np.abs(ref)), 1e-300)
     assert np.max(np.abs(got - ref)) <= 2e-4 * scale, (einstr, sizes)
+
+
+def _large_tile_case(rng):
+    """Random two-operand step whose operands are both unit-stride along their free index (k labels
+    first) - the shape class of the large-tile LDS-DMA kernel.  Returns (einsum, sizes)."""
+    from contractn_amd import einsum as E
+    for _ in range(200):
+        nm, nn, nk = int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 3))
+        m_l, n_l, k_l = list("ab"[:nm]), list("cd"[:nn]), list("ef"[:nk])
+        batch = ["x"] if rng.random() < 0.3 else []
+        sizes = {l: int(rng.choice([4, 8, 12, 16, 20, 32, 64])) for l in m_l + n_l}
+        sizes.update({l: int(rng.choice([2, 4, 8, 16, 32])) for l in k_l})
+        sizes.update({l: int(rng.choice([2, 3])) for l in batch})
+        ka, kb = list(k_l), list(k_l)
+        rng.shuffle(ka); rng.shuffle(kb)
+        ta = "".join(batch + ka + m_l)
+        tb = "".join(batch + kb + n_l)
+        out_m = list(m_l); rng.shuffle(out_m)                   # row labels of C in any order
+        einstr = f"{ta},{tb}->{''.join(batch + out_m + n_l)}"
+        shapes = tuple(tuple(sizes[c] for c in t) for t in (ta, tb))
+        clist = E._contract_path(einstr, shapes, optimize=((0, 1),), memory_limit=None, use_blas=True)
+        info = E._native_plan(clist, shapes, "float32").step_infos()[0]
+        if info["kernel"] == 2 and info["tile_m"] == 256:
+            return einstr, sizes
+    raise AssertionError("no eligible case generated")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_large_tile_steps_f32(seed, monkeypatch):
+    from contractn_amd import einsum as E
+    monkeypatch.setenv("CTN_MFMA_G", "2")       # take the large-tile kernel whenever the planner allows it
+    E.clear_caches()
+    rng = np.random.default_rng(9000 + seed)
+    einstr, sizes = _large_tile_case(rng)
+    lhs = einstr.split("->")[0].split(",")
+    ops = [rng.standard_normal([sizes[c] for c in t]).astype(np.float32) for t in lhs]
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    t_hat, c = contract(einstr, *ops, optimize=((0, 1),), split_format=True)
+    E.clear_caches()
+    got = t_hat.astype(np.float64) * np.exp(float(c))
+    assert got.shape == ref.shape, einstr
+    assert np.max(np.abs(got - ref)) <= 1e-4 * np.max(np.abs(ref)), (einstr, sizes)
