@@ -265,7 +265,7 @@ static int exec_launch_all(Exec* E) {
         // CTN_MFMA_G (read when the executor is created): 0 = never, 1 = 256x128 tiles when the launch
         // fills the chip (default), 2 = whenever eligible (tests), 3 / 4 = the 256x256 experiments
         const int use_g = E->mfma_g;
-        static_assert(GM == 256 && GN == kTileN && GK == 16, "planner eligibility rule (plan.cpp) assumes these");
+        static_assert(GM == 256 && GN == kTileN && GK == 16 && 2 * GK == 32, "planner eligibility rule (plan.cpp) assumes these");
         // ... and the launch has at least two of the big tiles per CU: with fewer, 128-row tiles spread the
         // same work over more CUs (measured: 2048^3 runs at 90 vs 56 TFLOP/s, 4096^3 at 125 vs 135)
         const int64_t gtiles = st.Bt * ((st.M + GM - 1) / GM) * a.tiles_n * R;

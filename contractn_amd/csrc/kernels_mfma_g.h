@@ -16,9 +16,9 @@ namespace ctn {
 //
 // Eligibility (decided by the planner, plan.cpp): both operands "mode 1" (unit stride along their
 // free index, so 16 bytes per lane are 4 consecutive rows/columns and a wave instruction fills one
-// lane-linear k-row of the LDS image), K % 16 == 0 (LDS-DMA cannot mask; ragged M / N only produce
-// rows and columns that the epilogue drops - padded tables keep their loads in bounds), K >= 32, C
-// vector-storable.  Everything else stays on k_mfma_f32.
+// lane-linear k-row of the LDS image), K >= 32, C vector-storable.  LDS-DMA cannot mask: padded tables
+// keep every load in bounds, ragged M / N only produce rows and columns that the epilogue drops, and
+// the rows of a ragged last k-tile are zeroed when they are read into fragments.  Everything else stays on k_mfma_f32.
 //
 // The MFMA is issued with the operands swapped (B fragment as SrcA), i.e. it accumulates C^T
 // blocks: a lane then holds 4 CONSECUTIVE columns of one row of C in 4 consecutive accumulator
@@ -101,7 +101,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   // with wave-uniform vector loads next to the LDS-DMA requests costs 2.5 % on the headline)
   const_i32_ptr okA = (const_i32_ptr)(a.okA + RPW * w);
   const_i32_ptr okB = (const_i32_ptr)(a.okB + RPW * w);
-  const int nkt = a.K / GK;
+  const int nkt = (a.K + GK - 1) / GK;
+  // ragged K: LDS-DMA cannot mask, so the last k-tile's rows beyond K hold in-bounds garbage (padded
+  // k-tables); they are zeroed when read into fragments - both operands, so nothing can turn into NaN
+  const bool ktail = (a.K % GK) != 0;
+  const int krem = a.K - (nkt - 1) * GK;
 
   int ka[RPW], kb[RPW];  // k-offset table entries of the next k-tile to request (wave-uniform)
 #pragma unroll
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
     const float* cB = smem + st_cur * STG + SZA + fb0;
     const float* nA = smem + st_nxt * STG + fa0;
     const float* nB = smem + st_nxt * STG + SZA + fb0;
+    const bool tail_cur = ktail && kt == nkt - 1, tail_nxt = ktail && kt + 2 == nkt;
 #pragma unroll
     for (int kk = 0; kk < GK / 2; ++kk) {
       const int c = kk & 1, nx = c ^ 1;
@@ -174,11 +179,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
         for (int i = 0; i < 4; ++i) fa[nx][i] = cA[(kk + 1) * 2 * GM + 32 * i];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) fb[nx][j] = cB[(kk + 1) * 2 * TNB + 32 * j];
+        if (tail_cur && 2 * (kk + 1) + h >= krem) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa[nx][i] = 0.f;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) fb[nx][j] = 0.f;
+        }
       } else if (kt + 1 < nkt) {  // first k-step of the next k-tile (published by this tile's barrier)
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[nx][i] = nA[32 * i];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) fb[nx][j] = nB[32 * j];
+        if (tail_nxt && h >= krem) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa[nx][i] = 0.f;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) fb[nx][j] = 0.f;
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)

@@ -306,12 +306,12 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       st.tileN = ((st.N + 63) / 64) * 64 < ((st.N + kTileN - 1) / kTileN) * kTileN ? 64 : kTileN;
       st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + st.tileN - 1) / st.tileN));
       // 256 x 128 tiles fed by LDS-DMA (kernels_mfma_g.h): both operands unit-stride along their free
-      // index, K a multiple of the 16-deep k-tile (LDS-DMA cannot mask), and M, N such that 256-row
+      // index, at least two 16-deep k-tiles, and M, N such that 256-row
       // tiles pad at most 15 % more than 128-row ones (ragged edges are masked in the epilogue).
       // blocks / partial slots stay counted in 128 x 128 units.
       const int64_t pad128 = round_up(st.M, kTileM) * round_up(st.N, kTileN);
       const int64_t pad256 = round_up(st.M, 256) * round_up(st.N, kTileN);
-      if (st.modeA == 1 && st.modeB == 1 && st.tileN == kTileN && st.cvec && st.K % 16 == 0 && st.K >= 32 &&
+      if (st.modeA == 1 && st.modeB == 1 && st.tileN == kTileN && st.cvec && st.K >= 32 &&
           st.M > kTileM && pad256 * 100 <= pad128 * 115)
         st.tileM = 256;
     } else if (kEnableMfmaF64 && P.dtype == CTN_F64 && tileable) {

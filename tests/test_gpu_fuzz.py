@@ -95,7 +95,7 @@ def _large_tile_case(rng):
         m_l, n_l, k_l = list("ab"[:nm]), list("cd"[:nn]), list("ef"[:nk])
         batch = ["x"] if rng.random() < 0.3 else []
         sizes = {l: int(rng.choice([4, 8, 12, 16, 20, 32, 64])) for l in m_l + n_l}
-        sizes.update({l: int(rng.choice([2, 4, 8, 16, 32])) for l in k_l})
+        sizes.update({l: int(rng.choice([2, 3, 4, 5, 8, 11, 16, 32])) for l in k_l})
         sizes.update({l: int(rng.choice([2, 3])) for l in batch})
         ka, kb = list(k_l), list(k_l)
         rng.shuffle(ka); rng.shuffle(kb)

@@ -263,6 +263,9 @@ def force_large_tiles(monkeypatch):
     ("km,kn->mn", [(48, 400), (48, 200)], None),                    # ragged M and N: masked edge tiles
     ("km,kn->mn", [(32, 896), (32, 196)], None),                    # 3.5 row tiles, ragged columns
     ("xkm,xkn->xmn", [(2, 64, 508), (2, 64, 128)], None),           # batch + 4 masked rows
+    ("km,kn->mn", [(33, 256), (33, 128)], None),                    # ragged K: 1 valid row in the last k-tile
+    ("km,kn->mn", [(100, 256), (100, 256)], None),                  # K = 6 k-tiles + 4
+    ("kam,kbn->ambn", [(47, 4, 100), (47, 2, 100)], None),          # everything ragged at once
 ])
 def test_large_tile_dma_kernel_vs_numpy(einstr, shapes, path, force_large_tiles):
     rng = np.random.default_rng(7)
