@@ -14,7 +14,7 @@ __device__ __forceinline__ float rnd(unsigned x) {
   return ((int)(x & 0xffffff) - 0x800000) * (1.0f / 0x800000) * 0.0625f;
 }
 
-template <int SHAPE, bool LDS>
+template <int SHAPE, bool LDS, int NV = 0>
 __global__ __launch_bounds__(256) void k_probe(float* out, unsigned long long* stamps, int iters) {
   __shared__ float sm[8192];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -26,10 +26,13 @@ __global__ __launch_bounds__(256) void k_probe(float* out, unsigned long long* s
   f32x4 a16[16];
   for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) a32[i][e] = 0.f;
   for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) a16[i][e] = 0.f;
+  int vv[8] = {tid, tid + 1, tid + 2, tid + 3, tid + 4, tid + 5, tid + 6, tid + 7};
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) asm volatile("v_add_u32 %0, %0, %1" : "+v"(vv[q & 7]) : "v"(tid));
       float x0, x1, y0, y1;
       if (LDS) {
         const int base = ((it * 8 + u) & 15) * 512;
@@ -56,23 +59,24 @@ __global__ __launch_bounds__(256) void k_probe(float* out, unsigned long long* s
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   float s = 0;
+  for (int q = 0; q < 8; ++q) s += (float)vv[q];
   for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) s += a32[i][e];
   for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) s += a16[i][e];
   out[blockIdx.x * blockDim.x + tid] = s;
   if (tid == 0) { stamps[blockIdx.x * 2] = t1 - t0; stamps[blockIdx.x * 2 + 1] = r1 - r0; }
 }
 
-template <int SHAPE, bool LDS>
+template <int SHAPE, bool LDS, int NV = 0>
 void run(int ncu, int wps) {
   const int iters = 12000, blocks = ncu * wps, threads = 256;
   float* out; unsigned long long* st;
   hipMalloc(&out, (size_t)blocks * threads * 4);
   hipMalloc(&st, (size_t)blocks * 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k_probe<SHAPE, LDS>), dim3(blocks), dim3(threads), 0, 0, out, st, iters);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k_probe<SHAPE, LDS, NV>), dim3(blocks), dim3(threads), 0, 0, out, st, iters);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  for (int w = 0; w < 4; ++w) hipLaunchKernelGGL((k_probe<SHAPE, LDS>), dim3(blocks), dim3(threads), 0, 0, out, st, iters);
+  for (int w = 0; w < 4; ++w) hipLaunchKernelGGL((k_probe<SHAPE, LDS, NV>), dim3(blocks), dim3(threads), 0, 0, out, st, iters);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 4;
   std::vector<unsigned long long> h(blocks * 2);
@@ -81,18 +85,19 @@ void run(int ncu, int wps) {
   for (int b = 0; b < blocks; ++b) clk.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 100.0);
   std::sort(clk.begin(), clk.end());
   const double flops = (double)blocks * 4 * iters * 8.0 * 4 * 4096.0;
-  printf("shape %dx%d %s waves/SIMD %d: %6.1f TFLOP/s  clock median %.0f MHz  kernel %.2f ms\n", SHAPE, SHAPE,
-         LDS ? "LDS-fed " : "reg-fed ", wps, flops / (ms * 1e-3) / 1e12, clk[clk.size() / 2], ms);
+  printf("shape %dx%d %s +%d VALU per 4 MFMA, waves/SIMD %d: %6.1f TFLOP/s  clock median %.0f MHz  kernel %.2f ms\n", SHAPE, SHAPE,
+         LDS ? "LDS-fed " : "reg-fed ", NV, wps, flops / (ms * 1e-3) / 1e12, clk[clk.size() / 2], ms);
   hipFree(out); hipFree(st);
 }
 
 int main() {
   int ncu = 256;
   hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
-  for (int rep = 0; rep < 2; ++rep)
+  for (int rep = 0; rep < 1; ++rep)
     for (int wps = 1; wps <= 2; ++wps) {
       run<32, false>(ncu, wps); run<16, false>(ncu, wps);
       run<32, true>(ncu, wps);  run<16, true>(ncu, wps);
+      run<32, true, 1>(ncu, wps); run<32, true, 2>(ncu, wps); run<32, true, 4>(ncu, wps); run<32, true, 8>(ncu, wps);
     }
   return 0;
 }
