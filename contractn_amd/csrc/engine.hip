@@ -279,8 +279,10 @@ static int exec_launch_all(Exec* E) {
             else hipLaunchKernelGGL((k_mfma_f32_g<4, 4>), g4, dim3(256), 0, E->stream, a);
           } else {
             a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
-            hipLaunchKernelGGL((k_mfma_f32_g<4, 2>), dim3((unsigned)((int64_t)a.blocks_per_replica * R)), dim3(256), 0,
-                               E->stream, a);
+            const dim3 gg((unsigned)((int64_t)a.blocks_per_replica * R));
+            static const bool no_asm = getenv("CTN_G_NO_ASM") != nullptr;   // development switch
+            if (st.K % GK == 0 && !no_asm) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true>), gg, dim3(256), 0, E->stream, a);
+            else hipLaunchKernelGGL((k_mfma_f32_g<4, 2, false>), gg, dim3(256), 0, E->stream, a);
           }
           break;
         }

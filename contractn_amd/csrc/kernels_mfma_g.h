@@ -4,6 +4,7 @@
 #include <type_traits>
 
 #include "kernels_mfma.h"
+#include "kernels_mfma_g_asm.inc"
 
 namespace ctn {
 
@@ -34,6 +35,9 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // compiler then uses scalar loads (lgkmcnt), which keeps them out of the vmcnt queue the ring counts on
 typedef const __attribute__((address_space(4))) int32_t* const_i32_ptr;
 
+// LDS byte address of a __shared__ element (DS instruction operand)
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(size_t)(lds_void_t*)p; }
+
 // one LDS-DMA wave instruction: lane l copies 16 bytes from its own global address to lds + 16 l
 __device__ __forceinline__ void glds16(const float* g, float* lds) {
   __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds, 16, 0, 0);
@@ -44,8 +48,10 @@ __device__ __forceinline__ void glds16(const float* g, float* lds) {
 //   <8, 2>: 256 x 256 tile, 8 waves as 2 x 4 of 128 x 64, 1 workgroup per CU
 //   <4, 4>: 256 x 256 tile, wave 128 x 128 (256 accumulator registers, one wave per SIMD): 8 LDS
 //           fragment reads per 16 MFMAs and a third less L2 -> LDS traffic per flop
-template <int NW, int NJ>
+// ASM: the k-steps run as the hand-scheduled blocks of kernels_mfma_g_asm.inc (<4, 2> and K % 16 == 0 only)
+template <int NW, int NJ, bool ASM = false>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_f32_g(StepArgs a) {
+  static_assert(!ASM || (NW == 4 && NJ == 2), "asm blocks exist for the 256 x 128 tile only");
   constexpr int WNC = NW / 2;                       // waves along N (2 along M)
   constexpr int TNB = WNC * 32 * NJ;                // tile columns
   constexpr int NREQ = 2 * (GK / NW);               // LDS-DMA instructions per wave and k-tile (TNB = 128: 4 + 2)
@@ -95,8 +101,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
 
   // loader: wave w fills k-rows RPW*w .. RPW*w + RPW-1 of every stage.  A row = 64 lanes x 4 rows of
   // the tile; B row (256 wide) likewise, or (128 wide) lanes 0-31 -> k-row, lanes 32-63 -> the next
-  const float* __restrict__ Ab = A + a.omA[m0 + 4 * lane];
-  const float* __restrict__ Bb = B + a.onB[n0 + 4 * (TNB == 128 ? l31 : lane)];
+  // addresses are kept as (wave-uniform 64-bit base) + (per-lane unsigned 32-bit byte offset): the
+  // scalar-base form of the load, so no vector-ALU address arithmetic per request (the planner only
+  // sends operands of at most 2^30 elements here, so byte offsets fit)
+  const uint32_t offA = (uint32_t)a.omA[m0 + 4 * lane] * 4u;
+  const uint32_t offB = (uint32_t)a.onB[n0 + 4 * (TNB == 128 ? l31 : lane)] * 4u;
+  const char* const Ac = reinterpret_cast<const char*>(A);
+  const char* const Bc = reinterpret_cast<const char*>(B);
   // k-offset table entries: scalar loads through the constant address space (measured: fetching them
   // with wave-uniform vector loads next to the LDS-DMA requests costs 2.5 % on the headline)
   const_i32_ptr okA = (const_i32_ptr)(a.okA + RPW * w);
@@ -114,14 +125,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   auto request = [&](int kt_next, int stage) {  // issue this wave's LDS-DMA loads of one k-tile, then look up the next offsets
     float* sa = smem + stage * STG + (RPW * w) * GM;
     float* sb = smem + stage * STG + SZA + (RPW * w) * TNB;
+    uint32_t oA = offA;
+    asm volatile("" : "+v"(oA));  // opaque: keeps (uniform base + k offset) + lane offset from being re-associated
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) glds16(Ab + ka[i], sa + i * GM);
-    if (TNB == 128) {
-      glds16(Bb + (h ? kb[1] : kb[0]), sb);
-      glds16(Bb + (h ? kb[3] : kb[2]), sb + 2 * TNB);
+    for (int i = 0; i < RPW; ++i)
+      glds16(reinterpret_cast<const float*>(Ac + (int64_t)ka[i] * 4 + oA), sa + i * GM);
+    if constexpr (TNB == 128) {
+      // lanes 0-31 fetch k-row 2p, lanes 32-63 k-row 2p+1: the smaller of the two table entries is the
+      // scalar base, the (non-negative) distance to the other one goes into that half's lane offset
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int lo = min(kb[2 * p], kb[2 * p + 1]);
+        const uint32_t d0 = (uint32_t)(kb[2 * p] - lo) * 4u, d1 = (uint32_t)(kb[2 * p + 1] - lo) * 4u;
+        glds16(reinterpret_cast<const float*>(Bc + (int64_t)lo * 4 + (offB + (h ? d1 : d0))), sb + 2 * p * TNB);
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) glds16(Bb + kb[i], sb + i * TNB);
+      for (int i = 0; i < RPW; ++i)
+        glds16(reinterpret_cast<const float*>(Bc + (int64_t)kb[i] * 4 + offB), sb + i * TNB);
     }
     const int k0 = kt_next * GK;  // the tables are padded by 64 entries past K
 #pragma unroll
@@ -165,6 +186,41 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
 #pragma unroll
     for (int j = 0; j < NJ; ++j) fb[0][j] = cB[32 * j];
   }
+  // <4, 2> with whole k-tiles: the k-steps run as hand-scheduled blocks (tools/gen_mfma_g_asm.py):
+  // single ds_read_b32 with immediate offsets (no address arithmetic on the vector ALU), the reads
+  // of step s+1 behind the first MFMA of step s, one wait per step, at its end.  The barrier / LDS-DMA
+  // section between the two halves of a k-tile stays in C++.
+  if constexpr (ASM) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[1][i] = 0.f;
+    fb[1][0] = fb[1][1] = 0.f;
+#define CTN_G_ASM_OPERANDS                                                                                      \
+    [a00] "+v"(acc[0][0]), [a01] "+v"(acc[0][1]), [a10] "+v"(acc[1][0]), [a11] "+v"(acc[1][1]),                \
+    [a20] "+v"(acc[2][0]), [a21] "+v"(acc[2][1]), [a30] "+v"(acc[3][0]), [a31] "+v"(acc[3][1]),                \
+    [fa00] "+v"(fa[0][0]), [fa01] "+v"(fa[0][1]), [fa02] "+v"(fa[0][2]), [fa03] "+v"(fa[0][3]),                \
+    [fa10] "+v"(fa[1][0]), [fa11] "+v"(fa[1][1]), [fa12] "+v"(fa[1][2]), [fa13] "+v"(fa[1][3]),                \
+    [fb00] "+v"(fb[0][0]), [fb01] "+v"(fb[0][1]), [fb10] "+v"(fb[1][0]), [fb11] "+v"(fb[1][1])
+    for (int kt = 0; kt < nkt; ++kt) {
+      const unsigned vA = lds_addr(smem + st_cur * STG + fa0), vB = lds_addr(smem + st_cur * STG + SZA + fb0);
+      const unsigned vAn = lds_addr(smem + st_nxt * STG + fa0), vBn = lds_addr(smem + st_nxt * STG + SZA + fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile(CTN_G_ASM_FIRST_HALF : CTN_G_ASM_OPERANDS : [vA] "v"(vA), [vB] "v"(vB) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xF70) /* vmcnt(0) */;  // k-tile kt+1: this wave's requests, a tile old
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nkt) request(kt + 3, st_req);
+      __builtin_amdgcn_sched_barrier(0);
+      // (the last k-tile also reads "next-tile" fragments: in-bounds LDS, never used - one code path,
+      // so the 128 accumulator registers stay pinned through the loop)
+      asm volatile(CTN_G_ASM_SECOND_HALF_NEXT : CTN_G_ASM_OPERANDS
+                   : [vA] "v"(vA), [vB] "v"(vB), [vAn] "v"(vAn), [vBn] "v"(vBn) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      st_cur = st_nxt;
+      st_nxt = st_req;
+      st_req = st_req == GST - 1 ? 0 : st_req + 1;
+    }
+#undef CTN_G_ASM_OPERANDS
+  } else
   for (int kt = 0; kt < nkt; ++kt) {
     const float* cA = smem + st_cur * STG + fa0;
     const float* cB = smem + st_cur * STG + SZA + fb0;

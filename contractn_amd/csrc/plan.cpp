@@ -312,7 +312,8 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       const int64_t pad128 = round_up(st.M, kTileM) * round_up(st.N, kTileN);
       const int64_t pad256 = round_up(st.M, 256) * round_up(st.N, kTileN);
       if (st.modeA == 1 && st.modeB == 1 && st.tileN == kTileN && st.cvec && st.K >= 32 &&
-          st.M > kTileM && pad256 * 100 <= pad128 * 115)
+          st.M > kTileM && pad256 * 100 <= pad128 * 115 &&
+          st.rhs >= 0 && P.tensors[st.lhs].numel <= (1LL << 30) && P.tensors[st.rhs].numel <= (1LL << 30))  // 32-bit byte offsets
         st.tileM = 256;
     } else if (kEnableMfmaF64 && P.dtype == CTN_F64 && tileable) {
       st.kernel = CTN_KERNEL_MFMA_F64;
