@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   static_assert(!ASM || (NW == 4 && NJ == 2), "asm blocks exist for the 256 x 128 tile only");
   constexpr int WNC = NW / 2;                       // waves along N (2 along M)
   constexpr int TNB = WNC * 32 * NJ;                // tile columns
-  constexpr int NREQ = 2 * (GK / NW);               // LDS-DMA instructions per wave and k-tile (TNB = 128: 4 + 2)
+  constexpr int NREQ = GK / NW + (TNB == 128 ? 2 : GK / NW);  // LDS-DMA instructions per wave and k-tile
   constexpr int SZA = GK * GM, SZB = GK * TNB, STG = SZA + SZB;
   constexpr int RPW = GK / NW;                      // k-rows of each operand tile loaded by one wave
   // ONE LDS object: [stage 0 A|B][stage 1 A|B][stage 2 A|B][red NW doubles]
@@ -79,9 +79,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 0] = __builtin_amdgcn_s_memtime();
 #endif
-  const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
-
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
   const float* __restrict__ B = (const float*)tp[a.idB] + a.obB[b];
@@ -90,22 +87,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = (w / WNC) * 128, wn = (w % WNC) * (32 * NJ);
 
-  // epilogue addressing, fetched before any LDS-DMA is in flight
-  int offm[4], offn[NJ][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) offm[i] = a.omC[m0 + wm + 32 * i + l31];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) offn[j][g] = a.onC[n0 + wn + 32 * j + 8 * g + 4 * h];
 
   // loader: wave w fills k-rows RPW*w .. RPW*w + RPW-1 of every stage.  A row = 64 lanes x 4 rows of
   // the tile; B row (256 wide) likewise, or (128 wide) lanes 0-31 -> k-row, lanes 32-63 -> the next
   // addresses are kept as (wave-uniform 64-bit base) + (per-lane unsigned 32-bit byte offset): the
   // scalar-base form of the load, so no vector-ALU address arithmetic per request (the planner only
   // sends operands of at most 2^30 elements here, so byte offsets fit)
-  const uint32_t offA = (uint32_t)a.omA[m0 + 4 * lane] * 4u;
-  const uint32_t offB = (uint32_t)a.onB[n0 + 4 * (TNB == 128 ? l31 : lane)] * 4u;
+  uint32_t offA = (uint32_t)a.omA[m0 + 4 * lane] * 4u;
+  uint32_t offB = (uint32_t)a.onB[n0 + 4 * (TNB == 128 ? l31 : lane)] * 4u;
+  // both table entries are "used" here, before the first LDS-DMA: a wait for an ordinary load that the
+  // compiler places after a request can only be vmcnt(0) and would also wait for the request to land
+  asm volatile("" : "+v"(offA), "+v"(offB));
   const char* const Ac = reinterpret_cast<const char*>(A);
   const char* const Bc = reinterpret_cast<const char*>(B);
   // k-offset table entries: scalar loads through the constant address space (measured: fetching them
@@ -159,10 +151,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
 
   request(1, 0);
   request(2, 1);                                   // nkt >= 2 is guaranteed by the launcher
-  // k-tile 0 has landed (this wave's share): all but the youngest request group
-  if (TNB == 128) __builtin_amdgcn_s_waitcnt(0xF76) /* vmcnt(6) */;
-  else if (NREQ == 4) __builtin_amdgcn_s_waitcnt(0xF74) /* vmcnt(4) */;
-  else __builtin_amdgcn_s_waitcnt(0xF78) /* vmcnt(8) */;
+  __builtin_amdgcn_sched_barrier(0);
+  // Everything the EPILOGUE needs is requested only now, behind the first two k-tiles, so that nothing
+  // but the operand addressing stands between the start of the workgroup and its first LDS-DMA: the
+  // producers' abs-sum partials (reduced to the rescale factors after the main loop; index clamped,
+  // lanes >= P masked there) and the C offset tables - 12 + (0..2) vector loads.
+  double pva = 0.0, pvb = 0.0;
+  if (a.partA) pva = a.partA[(size_t)r * kMaxPartials + min(lane, a.PA - 1)];
+  if (a.partB) pvb = a.partB[(size_t)r * kMaxPartials + min(lane, a.PB - 1)];
+  int offm[4], offn[NJ][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) offm[i] = a.omC[m0 + wm + 32 * i + l31];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) offn[j][g] = a.onC[n0 + wn + 32 * j + 8 * g + 4 * h];
+  __builtin_amdgcn_sched_barrier(0);
+  // k-tile 0 has landed (this wave's share): everything but the youngest request group and the (at
+  // least 4 + 4 NJ) epilogue loads behind it.  simm16 = vmcnt[3:0] | 7 << 4 | 15 << 8 | vmcnt[5:4] << 14
+  static_assert(NREQ + 4 + 4 * NJ == 18 || NREQ + 4 + 4 * NJ == 16 || NREQ + 4 + 4 * NJ == 28, "add the vmcnt immediate");
+  if (NREQ + 4 + 4 * NJ == 18) __builtin_amdgcn_s_waitcnt(0x4F72);       // vmcnt(18)
+  else if (NREQ + 4 + 4 * NJ == 16) __builtin_amdgcn_s_waitcnt(0x4F70);  // vmcnt(16)
+  else __builtin_amdgcn_s_waitcnt(0x4F7C);                               // vmcnt(28)
   __builtin_amdgcn_s_barrier();                    // ... and everybody else's
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 1] = __builtin_amdgcn_s_memtime();
@@ -281,6 +291,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
 #endif
   // epilogue: lazy rescale, 16-byte stores straight from the accumulators, abs-sum partial.
   // Ragged tiles (M % 256, N % 128) mask whole 16-byte vectors: N % 4 == 0 whenever C is vector-storable.
+  pva = lane < a.PA ? pva : 0.0;
+  pvb = lane < a.PB ? pvb : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { pva += __shfl_xor(pva, o, 64); pvb += __shfl_xor(pvb, o, 64); }
+  const float nA = (float)pva, nB = (float)pvb;  // exactly producer_scale<float>()
+  const float scA = (a.partA && nA > (float)a.min_norm) ? nA / (float)a.numelA : 1.f;
+  const float scB = (a.partB && nB > (float)a.min_norm) ? nB / (float)a.numelB : 1.f;
   const float iA = 1.0f / scA, iB = 1.0f / scB;
   float asum = 0.f;
   const bool full = (m0 + GM <= a.M) && (n0 + TNB <= a.N);
