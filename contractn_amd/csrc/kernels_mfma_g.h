@@ -12,8 +12,9 @@ namespace ctn {
 // K-mfma-f32-g: 256 x 128 workgroup tile, 4 waves (2x2), each wave 128 x 64 = 4 x 2
 // v_mfma_f32_32x32x2_f32 accumulators (6 LDS fragment reads per 8 MFMAs instead of 4 per 4), BK = 16.
 // Operand tiles go global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write
-// pass) into a 3-stage ring, two k-tiles ahead of the MFMAs; the only synchronisation per k-tile
-// is one counted s_waitcnt vmcnt + one raw s_barrier (a __syncthreads() would drain the ring).
+// pass) into a 3-stage ring, up to two k-tiles ahead of the MFMAs; the only synchronisation per
+// k-tile is one s_waitcnt vmcnt + one raw s_barrier in the MIDDLE of its MFMA phase (a
+// __syncthreads() would drain the ring).
 //
 // Eligibility (decided by the planner, plan.cpp): both operands "mode 1" (unit stride along their
 // free index, so 16 bytes per lane are 4 consecutive rows/columns and a wave instruction fills one
@@ -24,10 +25,9 @@ namespace ctn {
 // The MFMA is issued with the operands swapped (B fragment as SrcA), i.e. it accumulates C^T
 // blocks: a lane then holds 4 CONSECUTIVE columns of one row of C in 4 consecutive accumulator
 // registers, so the epilogue stores 16 bytes per lane straight from the accumulators - no LDS
-// staging, which keeps the ring alive (persistent variant) and the LDS budget at 72 KiB.
+// staging, LDS budget 72 KiB = two workgroups per CU.
 // ---------------------------------------------------------------------------
 constexpr int GM = 256, GN = 128, GK = 16, GST = 3;
-constexpr int G_SZA = GK * GM, G_SZB = GK * GN, G_STG = G_SZA + G_SZB;  // floats per ring stage (24 KiB)
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
