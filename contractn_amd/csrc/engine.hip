@@ -29,6 +29,7 @@
 #include "kernel_args.h"
 #include "kernels_mfma.h"
 #include "kernels_mfma_g.h"
+#include "kernels_mfma_g64.h"
 #include "kernels_stream.h"
 
 namespace ctn {
@@ -293,6 +294,15 @@ static int exec_launch_all(Exec* E) {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
         a.tiles_m = (int32_t)((st.M + kTile64M - 1) / kTile64M);
+        if (E->mfma_g && st.tileN == DN) {  // 128 x 128 LDS-DMA kernel, under the same launch-size rule as fp32
+          const int64_t gtiles = st.Bt * a.tiles_m * ((st.N + DN - 1) / DN) * R;
+          if (E->mfma_g >= 2 || gtiles >= 2LL * E->n_cu) {
+            a.tiles_n = (int32_t)((st.N + DN - 1) / DN);
+            a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
+            hipLaunchKernelGGL(k_mfma_f64_g, dim3((unsigned)gtiles), dim3(256), 0, E->stream, a);
+            break;
+          }
+        }
         a.tiles_n = (int32_t)((st.N + kTile64N - 1) / kTile64N);
         const dim3 g((unsigned)total), b(256);
 #define CTN_F64(AA, BB) hipLaunchKernelGGL((k_mfma_f64<AA, BB>), g, b, 0, E->stream, a)
@@ -482,7 +492,7 @@ int ctn_plan_step_info(const ctn_plan* plan, int step, ctn_step_info* info) {
   info->flops = s.flops;
   info->out_numel = plan->p.tensors[s.out].numel;
   info->tile_m = s.kernel == CTN_KERNEL_MFMA_F32 ? s.tileM : (s.kernel == CTN_KERNEL_MFMA_F64 ? kTile64M : 0);
-  info->tile_n = s.kernel == CTN_KERNEL_MFMA_F32 ? s.tileN : (s.kernel == CTN_KERNEL_MFMA_F64 ? kTile64N : 0);
+  info->tile_n = (s.kernel == CTN_KERNEL_MFMA_F32 || s.kernel == CTN_KERNEL_MFMA_F64) ? s.tileN : 0;
   return CTN_OK;
 }
 

@@ -86,7 +86,7 @@ def test_random_pairwise_step_f32_larger(seed):
     assert np.max(np.abs(got - ref)) <= 2e-4 * scale, (einstr, sizes)
 
 
-def _large_tile_case(rng):
+def _large_tile_case(rng, dtype="float32"):
     """Random two-operand step whose operands are both unit-stride along their free index (k labels
     first) - the shape class of the large-tile LDS-DMA kernel.  Returns (einsum, sizes)."""
     from contractn_amd import einsum as E
@@ -105,8 +105,8 @@ def _large_tile_case(rng):
         einstr = f"{ta},{tb}->{''.join(batch + out_m + n_l)}"
         shapes = tuple(tuple(sizes[c] for c in t) for t in (ta, tb))
         clist = E._contract_path(einstr, shapes, optimize=((0, 1),), memory_limit=None, use_blas=True)
-        info = E._native_plan(clist, shapes, "float32").step_infos()[0]
-        if info["kernel"] == 2 and info["tile_m"] == 256:
+        info = E._native_plan(clist, shapes, dtype).step_infos()[0]
+        if (info["kernel"] == 2 and info["tile_m"] == 256) or (info["kernel"] == 3 and info["tile_n"] == 128):
             return einstr, sizes
     raise AssertionError("no eligible case generated")
 
@@ -126,3 +126,20 @@ def test_random_large_tile_steps_f32(seed, monkeypatch):
     got = t_hat.astype(np.float64) * np.exp(float(c))
     assert got.shape == ref.shape, einstr
     assert np.max(np.abs(got - ref)) <= 1e-4 * np.max(np.abs(ref)), (einstr, sizes)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_large_tile_steps_f64(seed, monkeypatch):
+    from contractn_amd import einsum as E
+    monkeypatch.setenv("CTN_MFMA_G", "2")
+    E.clear_caches()
+    rng = np.random.default_rng(9500 + seed)
+    einstr, sizes = _large_tile_case(rng, "float64")
+    lhs = einstr.split("->")[0].split(",")
+    ops = [rng.standard_normal([sizes[c] for c in t]) for t in lhs]
+    ref = np.einsum(einstr, *ops)
+    t_hat, c = contract(einstr, *ops, optimize=((0, 1),), split_format=True)
+    E.clear_caches()
+    got = t_hat * np.exp(float(c))
+    assert got.shape == ref.shape, einstr
+    assert np.max(np.abs(got - ref)) <= 1e-11 * np.max(np.abs(ref)), (einstr, sizes)

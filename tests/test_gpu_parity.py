@@ -299,3 +299,29 @@ def test_large_tile_dma_kernel_replicas_and_exact_sums(force_large_tiles):
     assert np.array_equal(t[0], t[2]) and float(c[0]) == float(c[2])
     norm = np.abs(ref).sum()
     assert np.allclose(t[0].astype(np.float64), ref / (norm / ref.size), rtol=3e-7, atol=0)
+
+
+# --- the fp64 sibling (k_mfma_f64_g): 128 x 128 tiles, LDS-DMA ring ------------------------------------
+@pytest.mark.parametrize("einstr,shapes,path", [
+    ("km,kn->mn", [(16, 128), (16, 128)], None),                    # one tile, two k-tiles (ring minimum)
+    ("km,kn->mn", [(40, 256), (40, 256)], None),                    # 2 x 2 tiles, five k-tiles
+    ("km,kn->mn", [(19, 130), (19, 250)], None),                    # ragged M, N and K (3 valid rows in the last k-tile)
+    ("km,kn->mn", [(17, 128), (17, 128)], None),                    # one valid row in the last k-tile
+    ("xkm,xkn->xmn", [(2, 32, 128), (2, 32, 128)], None),           # batch (hyperedge) label
+    ("kam,kbn->ambn", [(24, 2, 64), (24, 2, 64)], None),            # composite free indices
+    ("km,kn,nj->mj", [(64, 128), (64, 128), (128, 128)], ((0, 1), (0, 1))),  # an operand = rescaled intermediate
+])
+def test_large_tile_dma_kernel_f64_vs_numpy(einstr, shapes, path, force_large_tiles):
+    rng = np.random.default_rng(17)
+    ops = [rng.standard_normal(s) * rng.uniform(0.5, 3.0) for s in shapes]
+    kw = {"optimize": path} if path is not None else {}
+    clist = E._contract_path(einstr, tuple(shapes), optimize=path if path is not None else "auto",
+                             memory_limit=None, use_blas=True)
+    info = E._native_plan(clist, tuple(shapes), "float64").step_infos()[-1]
+    assert info["kernel"] == 3 and info["tile_n"] == 128, info     # keeps this test on the kernel it is about
+    t_hat, c = contract(einstr, *ops, split_format=True, **kw)
+    ref = np.einsum(einstr, *ops)
+    got = t_hat * np.exp(float(c))
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref)) * 10
+    assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-13
