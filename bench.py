@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+PEAK_F64_MFMA_TFLOPS = 78.6   # half of it (secondary measurement: --dtype f64)
 
 
 def parse_args():
@@ -43,6 +44,8 @@ def parse_args():
     ap.add_argument("--event-passes", type=int, default=3, help="timed passes bracketed by HIP events")
     ap.add_argument("--dump-steps", default=None, help="write per-step kernel info + mean ms to this JSON file")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline time budget")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32",
+                    help="f32 = the BASELINE metric; f64 = the same workload in double precision (secondary)")
     return ap.parse_args()
 
 
@@ -94,7 +97,10 @@ def main():
     S = max(1, args.streams)
     assert R % S == 0, "--replicas must be a multiple of --streams"
     Rg = R // S
-    groups = [BatchedContraction(einstr, shapes, np.float32, optimize=path, replicas=Rg, device=local_rank)
+    f64 = args.dtype == "f64"
+    np_dt, t_dt, esz = (np.float64, torch.float64, 8) if f64 else (np.float32, torch.float32, 4)
+    peak = PEAK_F64_MFMA_TFLOPS if f64 else PEAK_F32_MFMA_TFLOPS
+    groups = [BatchedContraction(einstr, shapes, np_dt, optimize=path, replicas=Rg, device=local_rank)
               for _ in range(S)]
     bc = groups[0]
     plan, ex = bc.plan, bc.executor
@@ -108,11 +114,11 @@ def main():
     in_ptrs = []
     for r in range(R):
         gen.manual_seed(3 + r + 1000 * rank)
-        buf = torch.randn(int(offs[-1]), generator=gen, device=dev, dtype=torch.float32) / 16.0
+        buf = torch.randn(int(offs[-1]), generator=gen, device=dev, dtype=t_dt) / 16.0
         flat.append(buf)
         base = buf.data_ptr()
-        in_ptrs.extend(base + 4 * int(offs[i]) for i in range(len(shapes)))
-    out = torch.zeros(R, max(1, int(np.prod(plan.out_shape))), device=dev, dtype=torch.float32)
+        in_ptrs.extend(base + esz * int(offs[i]) for i in range(len(shapes)))
+    out = torch.zeros(R, max(1, int(np.prod(plan.out_shape))), device=dev, dtype=t_dt)
     out_ptrs = [out[r].data_ptr() for r in range(R)]
     n_in = len(shapes)
     launchers = [g.executor.make_enqueue(in_ptrs[i * Rg * n_in:(i + 1) * Rg * n_in], out_ptrs[i * Rg:(i + 1) * Rg])
@@ -165,7 +171,7 @@ def main():
     # ---- roofline of the dominant kernel (per launch, HIP-event durations) ---------------
     by_kernel = {}
     for s, info in enumerate(infos):
-        key = (info["kernel"], info["mode_a"], info["mode_b"], info["tile_m"])
+        key = (info["kernel"], info["mode_a"], info["mode_b"], info["tile_m"], info["tile_n"])
         d = by_kernel.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
         d["ms"] += step_ms_last[s]
         d["flops"] += info["flops"] * Rg
@@ -175,11 +181,11 @@ def main():
     from contractn_amd.engine import KERNEL_NAMES
 
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-    mfma_ms = sum(d["ms"] for k, d in by_kernel.items() if k[0] == 2)
-    mfma_flops = sum(d["flops"] for k, d in by_kernel.items() if k[0] == 2)
+    mfma_ms = sum(d["ms"] for k, d in by_kernel.items() if k[0] in (2, 3))
+    mfma_flops = sum(d["flops"] for k, d in by_kernel.items() if k[0] in (2, 3))
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile):
+    if os.path.exists(tfile) and not f64 and R == 512:   # the committed counters are for the default run
         try:
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         except Exception:
@@ -187,22 +193,23 @@ def main():
     roofline = {
         "bound": "mfma",
         "kernel": ("k_mfma_f32_g<4,2> (256x128 tiles, LDS-DMA ring)" if dom_key[0] == 2 and dom_key[3] == 256 else
+                   "k_mfma_f64_g (128x128 tiles, LDS-DMA ring)" if dom_key[0] == 3 and dom_key[4] == 128 else
                    f"k_{KERNEL_NAMES[dom_key[0]]}<modeA={dom_key[1]},modeB={dom_key[2]}>"),
         "achieved": round(achieved, 3),
-        "peak": PEAK_F32_MFMA_TFLOPS,
+        "peak": peak,
         "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        "frac": round(achieved / peak, 4),
         "traffic": traffic,
         "launches_per_step": dom["launches"],
         "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
         "flop_per_launch": dom["flops"] / max(dom["launches"], 1),
         "all_mfma_launches_tflops": round(mfma_flops / (mfma_ms * 1e-3) / 1e12, 3) if mfma_ms > 0 else None,
         "end_to_end_tflops": round(tflops / world, 3),
-        "end_to_end_frac": round(tflops / world / PEAK_F32_MFMA_TFLOPS, 4),
+        "end_to_end_frac": round(tflops / world / peak, 4),
     }
 
     result = {
-        "metric": "contractions/sec (MPS-100 overlap, bond=256, phys=4, fp32, stabilised split format)",
+        "metric": f"contractions/sec (MPS-100 overlap, bond=256, phys=4, {'fp64' if f64 else 'fp32'}, stabilised split format)",
         "value": round(value, 2),
         "unit": "contractions/s",
         "n_gpus": world,
@@ -212,7 +219,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,
         "data": "synthetic (standard normal / 16, on-device generator, seeds 3+replica)",
         "config": {
             "workload": f"mps_overlap_{args.sites}sites_D{args.bond}_d{args.phys}_zipper_R{R}",
