@@ -132,3 +132,27 @@ def test_raw_ctypes_error_reporting():
     handle = ctypes.c_void_p()
     rc = lib.ctn_plan_create(None, ctypes.byref(handle))
     assert rc == -1 and b"NULL" in lib.ctn_last_error()
+
+
+def test_planner_selects_large_tile_kernels():
+    """ctn_step_info.tile_m / tile_n: the planner's choice of the LDS-DMA large-tile kernels (host-only)."""
+    from contractn_amd import einsum as E
+
+    def info(einstr, shapes, dtype):
+        clist = E._contract_path(einstr, tuple(shapes), optimize=((0, 1),), memory_limit=None, use_blas=True)
+        return E._native_plan(clist, tuple(shapes), dtype).step_infos()[0]
+
+    # both operands unit-stride along their free index, full tiles: fp32 256 x 128, fp64 128 x 128
+    i = info("km,kn->mn", [(256, 256), (256, 1024)], "float32")
+    assert (i["kernel"], i["tile_m"], i["tile_n"]) == (2, 256, 128)
+    i = info("km,kn->mn", [(256, 256), (256, 1024)], "float64")
+    assert (i["kernel"], i["tile_m"], i["tile_n"]) == (3, 128, 128)
+    # ragged M / N / K are fine as long as 256-row tiles do not pad much more than 128-row ones
+    assert info("km,kn->mn", [(100, 400), (100, 200)], "float32")["tile_m"] == 256
+    assert info("km,kn->mn", [(100, 300), (100, 128)], "float32")["tile_m"] == 128      # 300 -> 512 rows: too much padding
+    # a k-contiguous (row-major) operand stays on the register-staged kernels
+    assert info("mk,kn->mn", [(256, 256), (256, 1024)], "float32")["tile_m"] == 128
+    assert info("mk,kn->mn", [(256, 256), (256, 1024)], "float64")["tile_n"] == 64
+    # fewer than two k-tiles
+    assert info("km,kn->mn", [(16, 256), (16, 256)], "float32")["tile_m"] == 128
+    assert info("km,kn->mn", [(8, 128), (8, 128)], "float64")["tile_n"] == 64
