@@ -212,6 +212,7 @@ static int exec_launch_all(Exec* E) {
     double* part_dst = E->d_partials + (size_t)s * R * kMaxPartials;
     a.partC = st.collapse ? E->d_scratch : part_dst;
     a.partC_stride = st.collapse ? st.blocks : kMaxPartials;
+    int collapse_blocks = st.blocks;   // partials written per replica when the step collapses (a launcher may retile)
     a.min_norm = P.min_norm;
     a.Bt = (int32_t)st.Bt; a.M = (int32_t)st.M; a.N = (int32_t)st.N; a.K = (int32_t)st.K;
     a.idA = st.lhs; a.idB = st.rhs >= 0 ? st.rhs : E->n_tensors - 1; a.idC = st.out;
@@ -287,6 +288,17 @@ static int exec_launch_all(Exec* E) {
           }
           break;
         }
+        // under-filled launch (fewer than two 128 x 128 tiles per CU, e.g. one network with a batch
+        // leg): 128 x 64 tiles double the workgroups.  Only for steps whose partials go through the
+        // collapse pass anyway (> 64 tiles per replica), where the tile count is not baked into the plan.
+        if (st.collapse && st.tileN == kTileN && total < 2LL * E->n_cu && st.N > 64) {
+          a.tiles_n = (int32_t)((st.N + 63) / 64);
+          collapse_blocks = (int)(st.Bt * a.tiles_m * a.tiles_n);
+          a.blocks_per_replica = collapse_blocks;
+          a.partC_stride = collapse_blocks;
+          launch_mfma(st.modeA, st.modeB, 64, dim3((unsigned)((int64_t)collapse_blocks * R)), E->stream, a);
+          break;
+        }
         launch_mfma(st.modeA, st.modeB, st.tileN, dim3((unsigned)total), E->stream, a);
         break;
       }
@@ -345,7 +357,7 @@ static int exec_launch_all(Exec* E) {
       }
     }
     if (st.collapse)
-      hipLaunchKernelGGL(k_collapse, dim3(R), dim3(256), 0, E->stream, (const double*)E->d_scratch, st.blocks, part_dst);
+      hipLaunchKernelGGL(k_collapse, dim3(R), dim3(256), 0, E->stream, (const double*)E->d_scratch, collapse_blocks, part_dst);
     if (timed) HIPCHECK(hipEventRecord(E->events[ev0 + 1], E->stream));
   }
   FinalArgs f;

@@ -385,7 +385,8 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     st.chain_ok = outs <= kChainMaxOut && outs * st.K <= kChainMaxWork;
     st.collapse = st.blocks > kMaxPartials;
     st.partials = st.collapse ? 1 : st.blocks;
-    if (st.collapse) P.max_collapse_blocks = std::max<int64_t>(P.max_collapse_blocks, st.blocks);
+    // (x2: the launcher may halve the column tile of an under-filled fp32 MFMA launch)
+    if (st.collapse) P.max_collapse_blocks = std::max<int64_t>(P.max_collapse_blocks, 2 * (int64_t)st.blocks);
     st.flops = (st.has_k ? 2.0 : 1.0) * (double)st.Bt * (double)st.M * (double)st.N * (double)st.K +
                (P.stabilize ? 3.0 * (double)out.numel : 0.0);
     P.flops += st.flops;
