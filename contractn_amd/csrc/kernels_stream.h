@@ -30,6 +30,9 @@ __device__ __forceinline__ void load_vec(const T* __restrict__ p, int stride_n, 
       const T x = p[0];
 #pragma unroll
       for (int v = 0; v < V; ++v) out[v] = x;
+    } else if (stride_n != 1) {   // strided along n: a gather of V elements (the other operand and C still use vectors)
+#pragma unroll
+      for (int v = 0; v < V; ++v) out[v] = p[(int64_t)v * stride_n];
     } else {
       typedef typename VecOf<T, V>::type VT;
       const VT x = *reinterpret_cast<const VT*>(p);

@@ -355,8 +355,9 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       build_table(lo, 0, st.L, t6); st.t.olA = append(P.tables, t6);
       build_table(lo, 1, st.L, t6); st.t.olB = append(P.tables, t6);
       build_table(lo, 2, st.L, t6); st.t.olC = append(P.tables, t6);
-      // 16-byte vectors along n: each operand is unit-stride or broadcast there, everything aligned
-      bool vok = nl && st.Nv % vec == 0 && (st.sAn == 0 || st.sAn == 1) && (st.sBn == 0 || st.sBn == 1);
+      // 16-byte vectors along n: C always, an operand when it is unit-stride there (then everything of it
+      // must be vector-aligned); a broadcast operand is one scalar, any other stride a gather of V scalars
+      bool vok = nl && st.Nv % vec == 0;
       for (auto& l : info) {
         if (&l == nl) continue;
         if (l.inC && l.sC % vec != 0) vok = false;
