@@ -170,8 +170,9 @@ def main():
 
     # ---- roofline of the dominant kernel (per launch, HIP-event durations) ---------------
     by_kernel = {}
+    tiles = ex.step_tiles()   # what the launcher actually ran (it may retile by replica count)
     for s, info in enumerate(infos):
-        key = (info["kernel"], info["mode_a"], info["mode_b"], info["tile_m"], info["tile_n"])
+        key = (info["kernel"], info["mode_a"], info["mode_b"], tiles[s][0], tiles[s][1])
         d = by_kernel.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
         d["ms"] += step_ms_last[s]
         d["flops"] += info["flops"] * Rg
@@ -192,9 +193,7 @@ def main():
             traffic = None
     roofline = {
         "bound": "mfma",
-        "kernel": ("k_mfma_f32_g<4,2> (256x128 tiles, LDS-DMA ring)" if dom_key[0] == 2 and dom_key[3] == 256 else
-                   "k_mfma_f64_g (128x128 tiles, LDS-DMA ring)" if dom_key[0] == 3 and dom_key[4] == 128 else
-                   f"k_{KERNEL_NAMES[dom_key[0]]}<modeA={dom_key[1]},modeB={dom_key[2]}>"),
+        "kernel": kernel_label(dom_key),
         "achieved": round(achieved, 3),
         "peak": peak,
         "unit": "TFLOP/s",
@@ -204,6 +203,11 @@ def main():
         "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
         "flop_per_launch": dom["flops"] / max(dom["launches"], 1),
         "all_mfma_launches_tflops": round(mfma_flops / (mfma_ms * 1e-3) / 1e12, 3) if mfma_ms > 0 else None,
+        "other_mfma_kernels": [
+            {"kernel": kernel_label(k), "launches_per_step": d["launches"],
+             "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2),
+             "achieved": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 3) if d["ms"] > 0 else None}
+            for k, d in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"]) if k[0] in (2, 3) and k != dom_key],
         "end_to_end_tflops": round(tflops / world, 3),
         "end_to_end_frac": round(tflops / world / peak, 4),
     }
@@ -241,6 +245,20 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def kernel_label(key):
+    """rocprof-visible kernel behind a (kernel kind, modeA, modeB, tile rows, tile columns) group."""
+    from contractn_amd.engine import KERNEL_NAMES
+
+    kind, ma, mb, tm, tn = key
+    if kind == 2 and tm == 256:
+        return f"k_mfma_f32_g<{'8' if tn == 256 else '4'},2,asm> ({tm}x{tn} tiles, LDS-DMA ring)"
+    if kind == 3 and tn == 128:
+        return "k_mfma_f64_g (128x128 tiles, LDS-DMA ring)"
+    if kind in (2, 3) and tm:
+        return f"k_{KERNEL_NAMES[kind]}<modeA={ma},modeB={mb}> ({tm}x{tn} tiles)"
+    return f"k_{KERNEL_NAMES[kind]}<modeA={ma},modeB={mb}>"
 
 
 def cpu_baseline(einstr, shapes, path, flat0, offs, numels, budget_s, gpu_t, gpu_c):

@@ -57,6 +57,7 @@ struct Exec {
   int n_tensors = 0;
   int n_cu = 256;
   int mfma_g = 1;        // CTN_MFMA_G at creation time (see exec_launch_all)
+  std::vector<int32_t> launched_tile;  // per step: (tile rows << 16 | tile columns) of the last enqueue's MFMA kernel, else 0
   char* d_ws = nullptr;
   int32_t* d_tables = nullptr;
   void** d_ptrs = nullptr;
@@ -234,6 +235,8 @@ static int exec_launch_all(Exec* E) {
     const bool timed = E->timing_runs < E->timing_slots;  // only the first `slots` enqueues are bracketed
     const size_t ev0 = timed ? ((size_t)E->timing_runs * P.n_steps + s) * 2 : 0;
     if (timed) HIPCHECK(hipEventRecord(E->events[ev0], E->stream));
+    if ((int)E->launched_tile.size() != P.n_steps) E->launched_tile.assign(P.n_steps, 0);
+    auto used_tile = [&](int tm, int tn) { E->launched_tile[s] = (tm << 16) | tn; };
     switch (st.kernel) {
       case CTN_KERNEL_MFMA_F32: {
         const int64_t total = (int64_t)st.blocks * R;
@@ -248,6 +251,7 @@ static int exec_launch_all(Exec* E) {
           sk.tiles_m = (int32_t)((st.M + 63) / 64);
           sk.tiles_n = (int32_t)((st.N + 63) / 64);
           sk.tiles_per_replica = (int32_t)(st.Bt * sk.tiles_m * sk.tiles_n);
+          used_tile(64, 64);
           launch_sk(st.modeA, st.modeB, dim3((unsigned)((int64_t)sk.tiles_per_replica * sk.S * R)), E->stream, a, sk);
           hipLaunchKernelGGL(k_splitk_reduce, dim3(E->step_partials[s], R), dim3(256), 0, E->stream, a, sk);
           break;
@@ -273,13 +277,28 @@ static int exec_launch_all(Exec* E) {
         const int64_t gtiles = st.Bt * ((st.M + GM - 1) / GM) * a.tiles_n * R;
         if (use_g && st.tileM == GM && a.c_vec && (use_g >= 2 || gtiles >= 2LL * E->n_cu)) {
           a.tiles_m = (int32_t)((st.M + GM - 1) / GM);
+          // long-K steps whose tiles are all full also exist as 256 x 256 tiles (8 waves, one workgroup per
+          // CU: a third less L2 -> LDS traffic; measured K = 1024: 133.9 vs 130.3 TFLOP/s, K = 256: 116.0 vs 116.7)
+          const bool big = use_g == 1 && st.M % 256 == 0 && st.N % 256 == 0 && st.K % GK == 0 && st.K >= 512 &&
+                           gtiles / 2 >= (int64_t)E->n_cu;
+          if (big) {
+            used_tile(256, 256);
+            a.tiles_n = (int32_t)(st.N / 256);
+            a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
+            hipLaunchKernelGGL((k_mfma_f32_g<8, 2, true>), dim3((unsigned)((int64_t)a.blocks_per_replica * R)), dim3(512), 0,
+                               E->stream, a);
+            break;
+          }
           if ((use_g == 3 || use_g == 4) && st.M % 256 == 0 && st.N % 256 == 0) {
+            used_tile(256, 256);
             a.tiles_n = (int32_t)(st.N / 256);
             a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
             const dim3 g4((unsigned)((int64_t)a.blocks_per_replica * R));
-            if (use_g == 3) hipLaunchKernelGGL((k_mfma_f32_g<8, 2>), g4, dim3(512), 0, E->stream, a);
+            if (use_g == 3 && st.K % GK == 0) hipLaunchKernelGGL((k_mfma_f32_g<8, 2, true>), g4, dim3(512), 0, E->stream, a);
+            else if (use_g == 3) hipLaunchKernelGGL((k_mfma_f32_g<8, 2>), g4, dim3(512), 0, E->stream, a);
             else hipLaunchKernelGGL((k_mfma_f32_g<4, 4>), g4, dim3(256), 0, E->stream, a);
           } else {
+            used_tile(256, 128);
             a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
             const dim3 gg((unsigned)((int64_t)a.blocks_per_replica * R));
             static const bool no_asm = getenv("CTN_G_NO_ASM") != nullptr;   // development switch
@@ -292,6 +311,7 @@ static int exec_launch_all(Exec* E) {
         // leg): 128 x 64 tiles double the workgroups.  Only for steps whose partials go through the
         // collapse pass anyway (> 64 tiles per replica), where the tile count is not baked into the plan.
         if (st.collapse && st.tileN == kTileN && total < 2LL * E->n_cu && st.N > 64) {
+          used_tile(128, 64);
           a.tiles_n = (int32_t)((st.N + 63) / 64);
           collapse_blocks = (int)(st.Bt * a.tiles_m * a.tiles_n);
           a.blocks_per_replica = collapse_blocks;
@@ -299,6 +319,7 @@ static int exec_launch_all(Exec* E) {
           launch_mfma(st.modeA, st.modeB, 64, dim3((unsigned)((int64_t)collapse_blocks * R)), E->stream, a);
           break;
         }
+        used_tile(128, st.tileN);
         launch_mfma(st.modeA, st.modeB, st.tileN, dim3((unsigned)total), E->stream, a);
         break;
       }
@@ -309,12 +330,14 @@ static int exec_launch_all(Exec* E) {
         if (E->mfma_g && st.tileN == DN) {  // 128 x 128 LDS-DMA kernel, under the same launch-size rule as fp32
           const int64_t gtiles = st.Bt * a.tiles_m * ((st.N + DN - 1) / DN) * R;
           if (E->mfma_g >= 2 || gtiles >= 2LL * E->n_cu) {
+            used_tile(128, 128);
             a.tiles_n = (int32_t)((st.N + DN - 1) / DN);
             a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
             hipLaunchKernelGGL(k_mfma_f64_g, dim3((unsigned)gtiles), dim3(256), 0, E->stream, a);
             break;
           }
         }
+        used_tile(128, 64);
         a.tiles_n = (int32_t)((st.N + kTile64N - 1) / kTile64N);
         const dim3 g((unsigned)total), b(256);
 #define CTN_F64(AA, BB) hipLaunchKernelGGL((k_mfma_f64<AA, BB>), g, b, 0, E->stream, a)
@@ -719,6 +742,14 @@ int ctn_exec_set_timing(ctn_exec* exec, int slots) {
   }
   E->timing_slots = slots;
   E->timing_runs = 0;
+  return CTN_OK;
+}
+
+int ctn_exec_step_tile(const ctn_exec* exec, int step, int32_t* tile_m, int32_t* tile_n) {
+  if (!exec || !tile_m || !tile_n || step < 0 || step >= exec->e.plan->n_steps) { g_err = "invalid step query"; return CTN_INVALID_ARG; }
+  const int32_t v = step < (int)exec->e.launched_tile.size() ? exec->e.launched_tile[step] : 0;
+  *tile_m = v >> 16;
+  *tile_n = v & 0xFFFF;
   return CTN_OK;
 }
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ void glds16(const float* g, float* lds) {
 // ASM: the k-steps run as the hand-scheduled blocks of kernels_mfma_g_asm.inc (<4, 2> and K % 16 == 0 only)
 template <int NW, int NJ, bool ASM = false>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_f32_g(StepArgs a) {
-  static_assert(!ASM || (NW == 4 && NJ == 2), "asm blocks exist for the 256 x 128 tile only");
+  static_assert(!ASM || NJ == 2, "asm blocks exist for the 128 x 64 wave tile only");
   constexpr int WNC = NW / 2;                       // waves along N (2 along M)
   constexpr int TNB = WNC * 32 * NJ;                // tile columns
   constexpr int NREQ = GK / NW + (TNB == 128 ? 2 : GK / NW);  // LDS-DMA instructions per wave and k-tile
@@ -214,7 +214,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
       const unsigned vA = lds_addr(smem + st_cur * STG + fa0), vB = lds_addr(smem + st_cur * STG + SZA + fb0);
       const unsigned vAn = lds_addr(smem + st_nxt * STG + fa0), vBn = lds_addr(smem + st_nxt * STG + SZA + fb0);
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile(CTN_G_ASM_FIRST_HALF : CTN_G_ASM_OPERANDS : [vA] "v"(vA), [vB] "v"(vB) : "memory");
+      if constexpr (TNB == 128)
+        asm volatile(CTN_G_ASM_FIRST_HALF_N128 : CTN_G_ASM_OPERANDS : [vA] "v"(vA), [vB] "v"(vB) : "memory");
+      else
+        asm volatile(CTN_G_ASM_FIRST_HALF_N256 : CTN_G_ASM_OPERANDS : [vA] "v"(vA), [vB] "v"(vB) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xF70) /* vmcnt(0) */;  // k-tile kt+1: this wave's requests, a tile old
       __builtin_amdgcn_s_barrier();
@@ -222,8 +225,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
       __builtin_amdgcn_sched_barrier(0);
       // (the last k-tile also reads "next-tile" fragments: in-bounds LDS, never used - one code path,
       // so the 128 accumulator registers stay pinned through the loop)
-      asm volatile(CTN_G_ASM_SECOND_HALF_NEXT : CTN_G_ASM_OPERANDS
-                   : [vA] "v"(vA), [vB] "v"(vB), [vAn] "v"(vAn), [vBn] "v"(vBn) : "memory");
+      if constexpr (TNB == 128)
+        asm volatile(CTN_G_ASM_SECOND_HALF_NEXT_N128 : CTN_G_ASM_OPERANDS
+                     : [vA] "v"(vA), [vB] "v"(vB), [vAn] "v"(vAn), [vBn] "v"(vBn) : "memory");
+      else
+        asm volatile(CTN_G_ASM_SECOND_HALF_NEXT_N256 : CTN_G_ASM_OPERANDS
+                     : [vA] "v"(vA), [vB] "v"(vB), [vAn] "v"(vAn), [vBn] "v"(vBn) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       st_cur = st_nxt;
       st_nxt = st_req;

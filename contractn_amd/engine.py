@@ -36,6 +36,7 @@ ABI_SYMBOLS = (
     "ctn_plan_workspace_bytes", "ctn_plan_step_info",
     "ctn_exec_create", "ctn_exec_destroy", "ctn_exec_run", "ctn_exec_enqueue",
     "ctn_exec_fetch", "ctn_exec_synchronize", "ctn_exec_set_timing", "ctn_exec_step_ms",
+    "ctn_exec_step_tile",
 )
 
 
@@ -146,6 +147,7 @@ def load_library():
         "ctn_exec_synchronize": (i32, [vp]),
         "ctn_exec_set_timing": (i32, [vp, i32]),
         "ctn_exec_step_ms": (i32, [vp, C.POINTER(C.c_float)]),
+        "ctn_exec_step_tile": (i32, [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -330,6 +332,15 @@ class Executor:
     def set_timing(self, slots):
         """Bracket every step of the next ``slots`` enqueues with HIP events (0 = off)."""
         _check(self._lib.ctn_exec_set_timing(self._h, int(slots)))
+
+    def step_tiles(self):
+        """(tile rows, tile columns) of the MFMA kernel the last enqueue launched per step ((0, 0) otherwise)."""
+        out = []
+        tm, tn = C.c_int32(0), C.c_int32(0)
+        for s in range(self.plan.n_steps):
+            _check(self._lib.ctn_exec_step_tile(self._h, s, C.byref(tm), C.byref(tn)))
+            out.append((tm.value, tn.value))
+        return out
 
     def step_ms(self):
         ms = np.zeros(self.plan.n_steps, dtype=np.float32)

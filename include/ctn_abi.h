@@ -149,6 +149,14 @@ int ctn_exec_fetch(ctn_exec* exec, double* log_scale, double* step_rescales);
 int ctn_exec_synchronize(ctn_exec* exec);
 
 /*
+ * Workgroup tile (rows, columns) of the MFMA kernel that the LAST enqueue launched for `step`
+ * (0, 0 for non-MFMA steps or before the first enqueue).  The planner's choice (ctn_step_info.tile_m/n)
+ * can be overridden at launch time by the number of replicas: few tiles -> 64 x 64 split-K or 128 x 64,
+ * many full long-K tiles -> 256 x 256.  Measurement tooling only (bench.py keys its per-kernel roofline on it).
+ */
+int ctn_exec_step_tile(const ctn_exec* exec, int step, int32_t* tile_m, int32_t* tile_n);
+
+/*
  * Per-step device timing with HIP events recorded on the executor's stream.
  * ctn_exec_set_timing(exec, slots): slots > 0 brackets every step's kernels of
  * the next `slots` enqueues with events (later enqueues run without events);
