@@ -325,3 +325,21 @@ def test_large_tile_dma_kernel_f64_vs_numpy(einstr, shapes, path, force_large_ti
     assert got.shape == ref.shape
     assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref)) * 10
     assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-13
+
+
+def test_launcher_retiles_by_replica_count():
+    """The planner's tile is a default: the launcher takes 256 x 256 tiles for long-K full steps once there is
+    a tile per CU, and the latency kernel's 64 x 64 tiles for a single small network (ctn_exec_step_tile)."""
+    rng = np.random.default_rng(23)
+    A = (rng.standard_normal((1024, 256)) / 8).astype(np.float32)
+    B = (rng.standard_normal((1024, 256)) / 8).astype(np.float32)
+    ref = A.T.astype(np.float64) @ B.astype(np.float64)
+    for replicas, tile in ((1, (64, 64)), (256, (256, 256))):
+        bc = E.BatchedContraction("km,kn->mn", [A.shape, B.shape], np.float32, optimize=((0, 1),), replicas=replicas)
+        t, c = bc.run_host([[A, B]] * replicas)
+        assert bc.executor.step_tiles() == [tile]
+        for r in (0, replicas - 1):
+            got = t[r].astype(np.float64) * np.exp(float(c[r]))
+            assert np.max(np.abs(got - ref)) <= 2e-5 * np.max(np.abs(ref)) * 10
+        assert np.array_equal(t[0], t[replicas - 1])
+        bc.executor.close()
