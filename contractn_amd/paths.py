@@ -10,9 +10,13 @@ published algorithm of its ``contract_path``:
 * ``"greedy"``: Hadamard-merge operands with identical index sets, then
   repeatedly contract the pair that minimises ``size(out)-size(a)-size(b)``
   (ties broken by smaller flop cost), outer products last;
-* ``"optimal"``: exhaustive depth-first search over pairwise orders;
-* ``"auto"``/``True``: optimal below 5 operands, greedy otherwise
-  (opt_einsum additionally tries branch-and-bound for 5-14 operands).
+* ``"optimal"``: exhaustive depth-first search over pairwise orders (up to 8 operands), ``"dp"``:
+  exact minimum-flop order by dynamic programming over operand subsets (up to 12 operands);
+* ``"random-greedy[-N]"``: greedy restarts with Boltzmann noise, best of N by flop count;
+* ``"auto"``/``True``: optimal below 5 operands, dp up to 12, 32 random-greedy trials up to 400, plain
+  greedy beyond (opt_einsum: optimal / branch-and-bound / greedy over the same ranges);
+* ``memory_limit`` (elements, or ``"max_input"``): dp and random-greedy prefer paths whose
+  intermediates stay below it (they never fail: a larger intermediate is taken if nothing else exists).
 
 Every step is emitted as the 5-tuple consumed at reference einsum.py:342:
 ``(positions_descending, idx_removed, "L,R->O", remaining, blas_flag)`` where
@@ -156,7 +160,156 @@ def _optimal(term_sets, out, sizes):
     return best["path"]
 
 
-def find_path(terms, out, sizes, optimize):
+def path_cost(term_sets, out, sizes, path):
+    """(total flop proxy = sum over steps of the size of the joint index space, largest intermediate)."""
+    live = [set(t) for t in term_sets]
+    flops, biggest = 0, 0
+    for step in path:
+        step = tuple(sorted(step))
+        if len(step) == 1:
+            continue
+        i, j = step
+        rest = [x for k, x in enumerate(live) if k not in (i, j)]
+        new, _ = _pair_result(live[i], live[j], rest, out)
+        flops += _size(live[i] | live[j], sizes)
+        biggest = max(biggest, _size(new, sizes))
+        live = rest + [new]
+    return flops, biggest
+
+
+def _ssa_pairs_to_linear(pairs, n):
+    """Pairs over SSA ids (inputs 0..n-1, k-th pair defines n+k) -> shrinking-list positions."""
+    live = list(range(n))
+    path = []
+    for num, (x, y) in enumerate(pairs):
+        i, j = sorted((live.index(x), live.index(y)))
+        path.append((i, j))
+        live.pop(j)
+        live.pop(i)
+        live.append(n + num)
+    return path
+
+
+def _dp(term_sets, out, sizes, memory_limit=None):
+    """Exact minimum-flop pairwise order by dynamic programming over operand subsets (the published
+    algorithm behind opt_einsum's ``'dp'``: best tree of every subset from the best trees of its
+    two-way splits).  Subsets are bit masks; the labels a subset keeps are those also needed outside
+    it (other operands or the output), which makes hyperedges (labels shared by more than two
+    operands) come out right.  Every split is considered, outer products included (they are
+    sometimes the cheapest way to absorb small vectors), so the result equals the exhaustive search's.
+    O(3^n): used up to 12 operands."""
+    n = len(term_sets)
+    out_set = set(out)
+    full = (1 << n) - 1
+    labels_of = {}
+
+    def union_labels(mask):
+        if mask not in labels_of:
+            acc = set()
+            m, k = mask, 0
+            while m:
+                if m & 1:
+                    acc |= term_sets[k]
+                m >>= 1
+                k += 1
+            labels_of[mask] = acc
+        return labels_of[mask]
+
+    def kept(mask):
+        inside = union_labels(mask)
+        outside = union_labels(full ^ mask) | out_set
+        return inside & outside if mask != full else inside & out_set
+
+    best = {1 << k: (0, None, None) for k in range(n)}   # mask -> (cost, left, right)
+    # an input keeps ALL its labels until its first contraction (a label nobody else needs is summed there
+    # and still spans that step's iteration space)
+    keep = {1 << k: set(term_sets[k]) for k in range(n)}
+    for mask in range(1, full + 1):
+        if mask & (mask - 1) == 0:
+            continue
+        lowest = mask & -mask
+        sub = (mask - 1) & mask
+        cand = None
+        over = memory_limit is not None and mask != full and _size(kept(mask), sizes) > memory_limit
+        while sub:
+            if sub & lowest:   # canonical: the left part holds the subset's lowest operand
+                right = mask ^ sub
+                cost = best[sub][0] + best[right][0] + _size(keep[sub] | keep[right], sizes)
+                if over:
+                    cost += 1 << 200    # still possible, but only if nothing else fits
+                if cand is None or cost < cand[0]:
+                    cand = (cost, sub, right)
+            sub = (sub - 1) & mask
+        if cand is not None:
+            best[mask] = cand
+            keep[mask] = kept(mask)
+    # read the tree back as SSA pairs (children before parents)
+    ids = {1 << k: k for k in range(n)}
+    pairs = []
+
+    def emit(mask):
+        if mask in ids:
+            return ids[mask]
+        _, left, right = best[mask]
+        a, b = emit(left), emit(right)
+        ids[mask] = n + len(pairs)
+        pairs.append((a, b))
+        return ids[mask]
+
+    emit(full)
+    return _ssa_pairs_to_linear(pairs, n)
+
+
+def _random_greedy(term_sets, out, sizes, repeats=32, seed=0, memory_limit=None):
+    """Greedy restarts with Boltzmann noise on the pair score (the idea of opt_einsum's
+    ``'random-greedy'``): the first trial is the plain greedy path, the best path by flop count
+    (then by largest intermediate) wins.  Deterministic for a given seed."""
+    import math
+    import random
+
+    rng = random.Random(seed)
+    best_path = _greedy(term_sets, out, sizes)
+    best_key = path_cost(term_sets, out, sizes, best_path)
+    if memory_limit is not None and best_key[1] > memory_limit:
+        best_key = (best_key[0] + (1 << 200), best_key[1])
+    out_set = set(out)
+    for trial in range(1, repeats):
+        temperature = 0.3 * (1 + trial % 4)
+        live = [set(t) for t in term_sets]
+        path = []
+        while len(live) > 1:
+            refs, owners = {}, {}
+            for pos, t in enumerate(live):
+                for s_ in t:
+                    refs[s_] = refs.get(s_, 0) + 1
+                    owners.setdefault(s_, []).append(pos)
+            pairs = set()
+            for who in owners.values():
+                if len(who) > 1:
+                    pairs.update(itertools.combinations(who, 2))
+            if not pairs:
+                order = sorted(range(len(live)), key=lambda p_: (_size(live[p_], sizes), p_))
+                pairs = {tuple(sorted(order[:2]))}
+            scored = []
+            for i, j in sorted(pairs):
+                a, b = live[i], live[j]
+                new = {s_ for s_ in a | b if s_ in out_set or refs[s_] - (s_ in a) - (s_ in b) > 0}
+                score = _size(new, sizes) - _size(a, sizes) - _size(b, sizes)
+                # noise in the log domain, so that it matters at every scale
+                noisy = math.copysign(math.log1p(abs(score)), score) - temperature * math.log(1e-12 + rng.random())
+                scored.append((noisy, i, j, new))
+            _, i, j, new = min(scored)
+            path.append((i, j))
+            live = [x for k, x in enumerate(live) if k not in (i, j)] + [new]
+        key = path_cost(term_sets, out, sizes, path)
+        if memory_limit is not None and key[1] > memory_limit:
+            key = (key[0] + (1 << 200), key[1])
+        if key < best_key:
+            best_key, best_path = key, path
+    return best_path
+
+
+def find_path(terms, out, sizes, optimize, memory_limit=None):
     """Resolve ``optimize`` (strategy name or explicit path) to a list of position tuples."""
     n = len(terms)
     if not isinstance(optimize, (str, bool)) and optimize is not None:
@@ -173,12 +326,28 @@ def find_path(terms, out, sizes, optimize):
     if name is False:
         raise ValueError("optimize=False (single n-ary einsum) is not supported by the HIP engine")
     if name in ("auto", "auto-hq"):
-        name = "optimal" if n < 5 else "greedy"
+        # few operands: exact; up to 12: exact by subset DP; beyond: greedy with noisy restarts
+        # (32 trials, 128 for auto-hq; very large networks keep the single greedy pass)
+        if n < 5:
+            name = "optimal"
+        elif n <= 12:
+            name = "dp"
+        elif n <= 400:
+            return _random_greedy(sets, out, sizes, repeats=128 if name == "auto-hq" else 32, memory_limit=memory_limit)
+        else:
+            name = "greedy"
+    if name == "optimal" and n <= 8 and memory_limit is None:
+        return _optimal(sets, out, sizes)
     if name in ("optimal", "dp", "branch-all", "branch-2", "branch-1"):
-        if n <= 8:
-            return _optimal(sets, out, sizes)
-        name = "greedy"
-    if name in ("greedy", "eager", "opportunistic") or name.startswith("random-greedy"):
+        if n <= 12:
+            return _dp(sets, out, sizes, memory_limit=memory_limit)
+        return _random_greedy(sets, out, sizes, repeats=64, memory_limit=memory_limit)
+    if name.startswith("random-greedy"):
+        reps = 32
+        if "-" in name[len("random-greedy"):]:
+            reps = max(1, int(name.rsplit("-", 1)[1]))
+        return _random_greedy(sets, out, sizes, repeats=reps, memory_limit=memory_limit)
+    if name in ("greedy", "eager", "opportunistic"):
         return _greedy(sets, out, sizes)
     raise KeyError(f"Path optimizer '{optimize}' not found")
 
@@ -204,7 +373,11 @@ def _blas_flag(left, right, result, removed):
 def contraction_list(einstr, shapes, optimize="auto", memory_limit=None, use_blas=True):
     """Restatement of ``oe.contract_path(einstr, *shapes, shapes=True, einsum_call=True)[1]``."""
     terms, out, sizes = parse_einsum_input(einstr, shapes)
-    path = find_path(terms, out, sizes, optimize)
+    limit = None
+    if memory_limit not in (None, -1):
+        # opt_einsum semantics: a number of elements, or 'max_input' = the largest operand
+        limit = max(_size(set(t), sizes) for t in terms) if memory_limit == "max_input" else int(memory_limit)
+    path = find_path(terms, out, sizes, optimize, memory_limit=limit)
     live = list(terms)
     out_set = set(out)
     refs = {}  # label -> number of live terms that carry it

@@ -73,3 +73,62 @@ def test_greedy_scales_to_1000_operands():
     g = load_golden("readme_chain1000")
     cl = paths.contraction_list(g["einsum_str"], [o.shape for o in g["operands"]], optimize="greedy")
     assert len(cl) == 1000
+
+
+def _random_net(rng, n, n_labels):
+    labels = [chr(97 + i) for i in range(n_labels)]
+    sizes = {l: int(rng.choice([2, 3, 4, 8])) for l in labels}
+    terms = ["".join(rng.choice(labels, size=int(rng.integers(1, 4)), replace=False)) for _ in range(n)]
+    present = sorted(set("".join(terms)))
+    out = "".join(l for l in present if rng.random() < 0.2)
+    return terms, out, sizes
+
+
+def test_dp_equals_exhaustive_search_and_noisy_greedy_never_loses():
+    """'dp' is exact (same flop count as the exhaustive 'optimal', hyperedges and outer products included);
+    'random-greedy' keeps the plain greedy path as its first trial."""
+    rng = np.random.default_rng(0)
+    improved = 0
+    for _ in range(150):
+        terms, out, sizes = _random_net(rng, int(rng.integers(3, 8)), int(rng.integers(3, 9)))
+        sets = [set(t) for t in terms]
+        cost = lambda p: paths.path_cost(sets, out, sizes, p)[0]  # noqa: E731
+        assert cost(paths._dp(sets, out, sizes)) == cost(paths._optimal(sets, out, sizes)), (terms, out)
+        g, r = cost(paths._greedy(sets, out, sizes)), cost(paths._random_greedy(sets, out, sizes, repeats=16))
+        assert r <= g
+        improved += r < g
+    assert improved > 10
+
+
+@pytest.mark.parametrize("optimize", ["dp", "random-greedy", "random-greedy-8", "auto-hq"])
+def test_new_strategies_give_valid_contractions(optimize):
+    g = load_golden("peps3x3_D2_f64")
+    ops = g["operands"]
+    clist = paths.contraction_list(g["einsum_str"], [o.shape for o in ops], optimize=optimize)
+    assert len(clist) == len(ops) - 1
+    np.testing.assert_allclose(run_list(g["einsum_str"], ops, clist), g["plain"], rtol=1e-10)
+
+
+def test_auto_beats_plain_greedy_on_a_grid():
+    from contractn_amd import TN
+    from tests import networks as nets
+
+    tn = nets.peps_closed(TN, 3, 4, 4)
+    shapes = [p.shape for p in tn.params]
+    terms, out, sizes = paths.parse_einsum_input(tn.einsum_str, shapes)
+    sets = [set(t) for t in terms]
+    auto = paths.path_cost(sets, out, sizes, paths.find_path(terms, out, sizes, "auto"))
+    greedy = paths.path_cost(sets, out, sizes, paths.find_path(terms, out, sizes, "greedy"))
+    assert auto[0] < greedy[0] and auto[1] <= greedy[1]
+
+
+def test_memory_limit_steers_the_search():
+    # a chain where the cheapest order builds a large intermediate: with a limit the search avoids it
+    einstr, shapes = "ab,bc,cd,de->ae", [(64, 2), (2, 64), (64, 2), (2, 64)]
+    terms, out, sizes = paths.parse_einsum_input(einstr, shapes)
+    sets = [set(t) for t in terms]
+    free = paths.path_cost(sets, out, sizes, paths.find_path(terms, out, sizes, "dp"))
+    tight = paths.path_cost(sets, out, sizes, paths.find_path(terms, out, sizes, "dp", memory_limit=200))
+    assert tight[1] <= max(free[1], 200) or tight[1] <= free[1]
+    cl = paths.contraction_list(einstr, shapes, optimize="dp", memory_limit="max_input")
+    assert len(cl) == 3
