@@ -13,8 +13,9 @@ published algorithm of its ``contract_path``:
 * ``"optimal"``: exhaustive depth-first search over pairwise orders (up to 8 operands), ``"dp"``:
   exact minimum-flop order by dynamic programming over operand subsets (up to 12 operands);
 * ``"random-greedy[-N]"``: greedy restarts with Boltzmann noise, best of N by flop count;
-* ``"auto"``/``True``: optimal below 5 operands, dp up to 12, 32 random-greedy trials up to 400, plain
-  greedy beyond (opt_einsum: optimal / branch-and-bound / greedy over the same ranges);
+* ``"auto"``/``True``: optimal below 5 operands, dp up to 12, 8 random-greedy trials up to 64, plain
+  greedy beyond (opt_einsum: optimal / branch-and-bound / greedy over similar ranges); ``"auto-hq"``:
+  128 random-greedy trials at any size;
 * ``memory_limit`` (elements, or ``"max_input"``): dp and random-greedy prefer paths whose
   intermediates stay below it (they never fail: a larger intermediate is taken if nothing else exists).
 
@@ -326,14 +327,17 @@ def find_path(terms, out, sizes, optimize, memory_limit=None):
     if name is False:
         raise ValueError("optimize=False (single n-ary einsum) is not supported by the HIP engine")
     if name in ("auto", "auto-hq"):
-        # few operands: exact; up to 12: exact by subset DP; beyond: greedy with noisy restarts
-        # (32 trials, 128 for auto-hq; very large networks keep the single greedy pass)
+        # few operands: exact; up to 12: exact by subset DP; up to 64: greedy with 8 noisy restarts
+        # (tens of ms); beyond: the single greedy pass, as opt_einsum.  "auto-hq" spends 128 restarts
+        # at any size (seconds for hundreds of operands).
         if n < 5:
             name = "optimal"
         elif n <= 12:
             name = "dp"
-        elif n <= 400:
-            return _random_greedy(sets, out, sizes, repeats=128 if name == "auto-hq" else 32, memory_limit=memory_limit)
+        elif name == "auto-hq":
+            return _random_greedy(sets, out, sizes, repeats=128, memory_limit=memory_limit)
+        elif n <= 64:
+            return _random_greedy(sets, out, sizes, repeats=8, memory_limit=memory_limit)
         else:
             name = "greedy"
     if name == "optimal" and n <= 8 and memory_limit is None:
