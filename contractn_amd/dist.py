@@ -53,6 +53,56 @@ def combine_split(parts):
     return total.astype(parts[0][0].dtype), np.asarray(c_star, dtype=np.float64)
 
 
+def choose_slices(einstr, shapes, optimize="auto", max_intermediate=None, min_slices=1, max_labels=12):
+    """Pick the labels to slice for a given path: greedily the contracted label whose removal shrinks the
+    largest intermediate most (ties: the least element count left above the target, then the least
+    total work; once the memory target is met, simply the least added work), until the largest
+    intermediate is at most ``max_intermediate`` elements AND there are at least ``min_slices`` slices
+    (e.g. one per GPU).  Returns ``(labels, report)`` with the largest intermediate, the slice count and the
+    work overhead ``total sliced flop proxy / unsliced flop proxy`` - slicing a label that only part of the
+    path carries repeats the rest of the path for every value, so the overhead tells when a different
+    path (``optimize``) should be tried before more labels are sliced.  Host-only; the path is fixed."""
+    shapes = [tuple(int(d) for d in s) for s in shapes]
+    terms, out, sizes = paths.parse_einsum_input(einstr, shapes)
+    path = paths.find_path(terms, out, sizes, optimize)
+    sets = [set(t) for t in terms]
+    base_flops, base_big = paths.path_cost(sets, out, sizes, path)
+
+    def evaluate(labels):
+        sz = dict(sizes)
+        count = 1
+        for lab in labels:
+            count *= sizes[lab]
+            sz[lab] = 1
+        flops, inter = paths.path_profile(sets, out, sz, path)
+        big = max(inter, default=1)
+        # what still sticks out above the target (all of it when there is no target): the greedy step
+        # needs a measure that moves even when no single label lowers the peak
+        excess = sum(x for x in inter if max_intermediate is None or x > max_intermediate)
+        return flops * count, big, count, excess
+
+    chosen = []
+    flops, big, count = base_flops, base_big, 1
+    candidates = sorted(s for s in sizes if s not in out and sizes[s] > 1)
+    while (max_intermediate is not None and big > max_intermediate) or count < min_slices:
+        if len(chosen) >= max_labels:
+            break
+        best = None
+        for lab in candidates:
+            if lab in chosen:
+                continue
+            f, b, c, x = evaluate(chosen + [lab])
+            key = (b, x, f, lab) if max_intermediate is not None and big > max_intermediate else (f, lab)
+            if best is None or key < best[0]:
+                best = (key, lab, f, b, c)
+        if best is None:
+            break
+        _, lab, flops, big, count = best
+        chosen.append(lab)
+    return tuple(chosen), {"slices": count, "largest_intermediate": big, "unsliced_largest_intermediate": base_big,
+                           "work_overhead": flops / max(base_flops, 1)}
+
+
 def slice_network(einstr, operands, slice_labels):
     """Yield ``(index tuple, sliced einsum string, sliced operands)`` for every joint
     value of ``slice_labels`` (labels must be contracted, i.e. absent from the output)."""

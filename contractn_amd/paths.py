@@ -178,6 +178,23 @@ def path_cost(term_sets, out, sizes, path):
     return flops, biggest
 
 
+def path_profile(term_sets, out, sizes, path):
+    """(flop proxy, list of every intermediate's element count) of a path."""
+    live = [set(t) for t in term_sets]
+    flops, inter = 0, []
+    for step in path:
+        step = tuple(sorted(step))
+        if len(step) == 1:
+            continue
+        i, j = step
+        rest = [x for k, x in enumerate(live) if k not in (i, j)]
+        new, _ = _pair_result(live[i], live[j], rest, out)
+        flops += _size(live[i] | live[j], sizes)
+        inter.append(_size(new, sizes))
+        live = rest + [new]
+    return flops, inter
+
+
 def _ssa_pairs_to_linear(pairs, n):
     """Pairs over SSA ids (inputs 0..n-1, k-th pair defines n+k) -> shrinking-list positions."""
     live = list(range(n))

@@ -90,3 +90,24 @@ def test_world_size_2_gloo_join(name, nlab):
     # every rank holds the same joined result
     np.testing.assert_array_equal(results[0][1], results[1][1])
     assert results[0][2] == results[1][2]
+
+
+def test_choose_slices_bounds_memory_and_feeds_the_sliced_contraction():
+    """Automatic slice selection: bounds the largest intermediate / provides enough slices, and the labels it
+    returns give the same value through the sliced path as the unsliced contraction."""
+    from contractn_amd import TN, dist
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+
+    tn = nets.peps_closed(TN, 3, 3, 3, dtype=np.float64, seed=6)
+    ops = list(tn.params)
+    shapes = [o.shape for o in ops]
+    path = ssa_to_linear(nets.peps_row_path(3, 3), 18)
+    labels, rep = dist.choose_slices(tn.einsum_str, shapes, optimize=path, max_intermediate=9, min_slices=8)
+    assert rep["largest_intermediate"] <= 9 < rep["unsliced_largest_intermediate"]
+    assert rep["slices"] >= 8 and rep["work_overhead"] >= 1.0
+    assert all(lab not in tn.einsum_str.split("->")[1] for lab in labels)
+
+    t_s, c_s = dist.contract_sliced(tn.einsum_str, ops, labels, contract_fn=oracle_contract)
+    t_u, c_u = oracle_contract(tn.einsum_str, *ops)
+    np.testing.assert_allclose(np.asarray(t_s) * np.exp(float(c_s)), np.asarray(t_u) * np.exp(float(c_u)), rtol=1e-10)
