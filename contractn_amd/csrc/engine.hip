@@ -275,11 +275,13 @@ static int exec_launch_all(Exec* E) {
         // ... and the launch has at least two of the big tiles per CU: with fewer, 128-row tiles spread the
         // same work over more CUs (measured: 2048^3 runs at 90 vs 56 TFLOP/s, 4096^3 at 125 vs 135)
         const int64_t gtiles = st.Bt * ((st.M + GM - 1) / GM) * a.tiles_n * R;
-        if (use_g && st.tileM == GM && a.c_vec && (use_g >= 2 || gtiles >= 2LL * E->n_cu)) {
+        static const bool no_asm = getenv("CTN_G_NO_ASM") != nullptr;   // development switch
+        const bool kcontig = st.modeA == 2 || st.modeB == 2;            // exists only as hand-scheduled blocks
+        if (use_g && st.tileM == GM && a.c_vec && (use_g >= 2 || gtiles >= 2LL * E->n_cu) && !(kcontig && no_asm)) {
           a.tiles_m = (int32_t)((st.M + GM - 1) / GM);
           // long-K steps whose tiles are all full also exist as 256 x 256 tiles (8 waves, one workgroup per
           // CU: a third less L2 -> LDS traffic; measured K = 1024: 133.9 vs 130.3 TFLOP/s, K = 256: 116.0 vs 116.7)
-          const bool big = use_g == 1 && st.M % 256 == 0 && st.N % 256 == 0 && st.K % GK == 0 && st.K >= 512 &&
+          const bool big = use_g == 1 && !kcontig && st.M % 256 == 0 && st.N % 256 == 0 && st.K % GK == 0 && st.K >= 512 &&
                            gtiles / 2 >= (int64_t)E->n_cu;
           if (big) {
             used_tile(256, 256);
@@ -289,7 +291,7 @@ static int exec_launch_all(Exec* E) {
                                E->stream, a);
             break;
           }
-          if ((use_g == 3 || use_g == 4) && st.M % 256 == 0 && st.N % 256 == 0) {
+          if ((use_g == 3 || use_g == 4) && !kcontig && st.M % 256 == 0 && st.N % 256 == 0) {
             used_tile(256, 256);
             a.tiles_n = (int32_t)(st.N / 256);
             a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
@@ -301,8 +303,10 @@ static int exec_launch_all(Exec* E) {
             used_tile(256, 128);
             a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
             const dim3 gg((unsigned)((int64_t)a.blocks_per_replica * R));
-            static const bool no_asm = getenv("CTN_G_NO_ASM") != nullptr;   // development switch
-            if (st.K % GK == 0 && !no_asm) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true>), gg, dim3(256), 0, E->stream, a);
+            if (st.modeA == 2 && st.modeB == 1) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, 2, 1>), gg, dim3(256), 0, E->stream, a);
+            else if (st.modeA == 1 && st.modeB == 2) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, 1, 2>), gg, dim3(256), 0, E->stream, a);
+            else if (kcontig) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, 2, 2>), gg, dim3(256), 0, E->stream, a);
+            else if (st.K % GK == 0 && !no_asm) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true>), gg, dim3(256), 0, E->stream, a);
             else hipLaunchKernelGGL((k_mfma_f32_g<4, 2, false>), gg, dim3(256), 0, E->stream, a);
           }
           break;

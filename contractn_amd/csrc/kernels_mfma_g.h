@@ -49,9 +49,14 @@ __device__ __forceinline__ void glds16(const float* g, float* lds) {
 //   <4, 4>: 256 x 256 tile, wave 128 x 128 (256 accumulator registers, one wave per SIMD): 8 LDS
 //           fragment reads per 16 MFMAs and a third less L2 -> LDS traffic per flop
 // ASM: the k-steps run as the hand-scheduled blocks of kernels_mfma_g_asm.inc (<4, 2> and K % 16 == 0 only)
-template <int NW, int NJ, bool ASM = false>
+// MA / MB = 2: the operand is unit-stride along k instead ("mode 2", e.g. a row-major A): its 16-byte requests
+// run along k (one lane = one row, 4 consecutive k), its LDS image is [k / 4][rows][4], and both operands
+// are read in the permuted k order described in tools/gen_mfma_g_asm.py.  <4, 2, asm> only.
+template <int NW, int NJ, bool ASM = false, int MA = 1, int MB = 1>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_f32_g(StepArgs a) {
   static_assert(!ASM || NJ == 2, "asm blocks exist for the 128 x 64 wave tile only");
+  static_assert((MA == 1 && MB == 1) || (ASM && NW == 4 && NJ == 2), "k-contiguous operands: <4, 2, asm> only");
+  constexpr bool PERM = MA == 2 || MB == 2;         // permuted k order (see the generator)
   constexpr int WNC = NW / 2;                       // waves along N (2 along M)
   constexpr int TNB = WNC * 32 * NJ;                // tile columns
   constexpr int NREQ = GK / NW + (TNB == 128 ? 2 : GK / NW);  // LDS-DMA instructions per wave and k-tile
@@ -98,6 +103,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   // both table entries are "used" here, before the first LDS-DMA: a wait for an ordinary load that the
   // compiler places after a request can only be vmcnt(0) and would also wait for the request to land
   asm volatile("" : "+v"(offA), "+v"(offB));
+  uint32_t offA2[MA == 2 ? 4 : 1] = {0}, offB2[MB == 2 ? 2 : 1] = {0};   // k-contiguous operand: lane = row 64 q + lane
+  if constexpr (MA == 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) offA2[q] = (uint32_t)a.omA[m0 + 64 * q + lane] * 4u;
+    asm volatile("" : "+v"(offA2[0]), "+v"(offA2[1]), "+v"(offA2[2]), "+v"(offA2[3]));
+  }
+  if constexpr (MB == 2) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) offB2[q] = (uint32_t)a.onB[n0 + 64 * q + lane] * 4u;
+    asm volatile("" : "+v"(offB2[0]), "+v"(offB2[1]));
+  }
   const char* const Ac = reinterpret_cast<const char*>(A);
   const char* const Bc = reinterpret_cast<const char*>(B);
   // k-offset table entries: scalar loads through the constant address space (measured: fetching them
@@ -119,10 +135,26 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
     float* sb = smem + stage * STG + SZA + (RPW * w) * TNB;
     uint32_t oA = offA;
     asm volatile("" : "+v"(oA));  // opaque: keeps (uniform base + k offset) + lane offset from being re-associated
+    if constexpr (MA == 2) {      // wave w brings k-chunk w (k = 4w .. 4w+3) of all 256 rows: 4 requests of 64 rows
 #pragma unroll
-    for (int i = 0; i < RPW; ++i)
-      glds16(reinterpret_cast<const float*>(Ac + (int64_t)ka[i] * 4 + oA), sa + i * GM);
-    if constexpr (TNB == 128) {
+      for (int q = 0; q < 4; ++q) {
+        uint32_t o = offA2[q];
+        asm volatile("" : "+v"(o));
+        glds16(reinterpret_cast<const float*>(Ac + (int64_t)ka[0] * 4 + o), smem + stage * STG + (w * GM + 64 * q) * 4);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i)
+        glds16(reinterpret_cast<const float*>(Ac + (int64_t)ka[i] * 4 + oA), sa + i * GM);
+    }
+    if constexpr (MB == 2) {      // k-chunk w of all 128 columns: 2 requests of 64 columns
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        uint32_t o = offB2[q];
+        asm volatile("" : "+v"(o));
+        glds16(reinterpret_cast<const float*>(Bc + (int64_t)kb[0] * 4 + o), smem + stage * STG + SZA + (w * TNB + 64 * q) * 4);
+      }
+    } else if constexpr (TNB == 128) {
       // lanes 0-31 fetch k-row 2p, lanes 32-63 k-row 2p+1: the smaller of the two table entries is the
       // scalar base, the (non-negative) distance to the other one goes into that half's lane offset
 #pragma unroll
@@ -184,17 +216,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   // after that follow it (every wave has left the previous k-tile, so its ring stage is free).  The
   // fragment read-ahead therefore runs straight across the k-tile boundary and a wave never waits
   // on LDS or on its peers with an empty matrix pipe.
-  const int fa0 = h * GM + wm + l31;
-  const int fb0 = h * TNB + wn + l31;
+  // this lane's fragment base inside an operand tile, in floats (lane-half h folded in), and the distance
+  // between 32-row fragment blocks: layout [k][rows] (k = 2 kk + h, or 8 (kk / 4) + 4 h + kk % 4 when
+  // permuted), resp. [k / 4][rows][4] for a k-contiguous operand
+  const int fa0 = MA == 2 ? (h * GM + wm + l31) * 4 : ((PERM ? 4 * h : h) * GM + wm + l31);
+  const int fb0 = MB == 2 ? (h * TNB + wn + l31) * 4 : ((PERM ? 4 * h : h) * TNB + wn + l31);
+  constexpr int blkA = MA == 2 ? 128 : 32, blkB = MB == 2 ? 128 : 32;
   int st_cur = 0, st_nxt = 1, st_req = 2;
   float fa[2][4], fb[2][NJ];
   {
     const float* cA = smem + fa0;
     const float* cB = smem + SZA + fb0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[0][i] = cA[32 * i];
+    for (int i = 0; i < 4; ++i) fa[0][i] = cA[blkA * i];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) fb[0][j] = cB[32 * j];
+    for (int j = 0; j < NJ; ++j) fb[0][j] = cB[blkB * j];
   }
   // <4, 2> with whole k-tiles: the k-steps run as hand-scheduled blocks (tools/gen_mfma_g_asm.py):
   // single ds_read_b32 with immediate offsets (no address arithmetic on the vector ALU), the reads
@@ -214,7 +250,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
       const unsigned vA = lds_addr(smem + st_cur * STG + fa0), vB = lds_addr(smem + st_cur * STG + SZA + fb0);
       const unsigned vAn = lds_addr(smem + st_nxt * STG + fa0), vBn = lds_addr(smem + st_nxt * STG + SZA + fb0);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (TNB == 128)
+      if constexpr (MA == 2 && MB == 1)
+        asm volatile(CTN_G_ASM_FIRST_HALF_N128_A2B1 : CTN_G_ASM_OPERANDS : [vA] "v"(vA), [vB] "v"(vB) : "memory");
+      else if constexpr (MA == 1 && MB == 2)
+        asm volatile(CTN_G_ASM_FIRST_HALF_N128_A1B2 : CTN_G_ASM_OPERANDS : [vA] "v"(vA), [vB] "v"(vB) : "memory");
+      else if constexpr (MA == 2 && MB == 2)
+        asm volatile(CTN_G_ASM_FIRST_HALF_N128_A2B2 : CTN_G_ASM_OPERANDS : [vA] "v"(vA), [vB] "v"(vB) : "memory");
+      else if constexpr (TNB == 128)
         asm volatile(CTN_G_ASM_FIRST_HALF_N128 : CTN_G_ASM_OPERANDS : [vA] "v"(vA), [vB] "v"(vB) : "memory");
       else
         asm volatile(CTN_G_ASM_FIRST_HALF_N256 : CTN_G_ASM_OPERANDS : [vA] "v"(vA), [vB] "v"(vB) : "memory");
@@ -225,7 +267,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
       __builtin_amdgcn_sched_barrier(0);
       // (the last k-tile also reads "next-tile" fragments: in-bounds LDS, never used - one code path,
       // so the 128 accumulator registers stay pinned through the loop)
-      if constexpr (TNB == 128)
+      if constexpr (MA == 2 && MB == 1)
+        asm volatile(CTN_G_ASM_SECOND_HALF_NEXT_N128_A2B1 : CTN_G_ASM_OPERANDS
+                     : [vA] "v"(vA), [vB] "v"(vB), [vAn] "v"(vAn), [vBn] "v"(vBn) : "memory");
+      else if constexpr (MA == 1 && MB == 2)
+        asm volatile(CTN_G_ASM_SECOND_HALF_NEXT_N128_A1B2 : CTN_G_ASM_OPERANDS
+                     : [vA] "v"(vA), [vB] "v"(vB), [vAn] "v"(vAn), [vBn] "v"(vBn) : "memory");
+      else if constexpr (MA == 2 && MB == 2)
+        asm volatile(CTN_G_ASM_SECOND_HALF_NEXT_N128_A2B2 : CTN_G_ASM_OPERANDS
+                     : [vA] "v"(vA), [vB] "v"(vB), [vAn] "v"(vAn), [vBn] "v"(vBn) : "memory");
+      else if constexpr (TNB == 128)
         asm volatile(CTN_G_ASM_SECOND_HALF_NEXT_N128 : CTN_G_ASM_OPERANDS
                      : [vA] "v"(vA), [vB] "v"(vB), [vAn] "v"(vAn), [vBn] "v"(vBn) : "memory");
       else

@@ -305,13 +305,15 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       // 64-wide column tiles when they cover N with less padding (e.g. N = 64, 192, 320)
       st.tileN = ((st.N + 63) / 64) * 64 < ((st.N + kTileN - 1) / kTileN) * kTileN ? 64 : kTileN;
       st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + st.tileN - 1) / st.tileN));
-      // 256 x 128 tiles fed by LDS-DMA (kernels_mfma_g.h): both operands unit-stride along their free
-      // index, at least two 16-deep k-tiles, and M, N such that 256-row
+      // 256 x 128 tiles fed by LDS-DMA (kernels_mfma_g.h): each operand unit-stride along its free index
+      // or along k (16-byte requests either way; not the general gather), at least two 16-deep k-tiles,
+      // and M, N such that 256-row
       // tiles pad at most 15 % more than 128-row ones (ragged edges are masked in the epilogue).
       // blocks / partial slots stay counted in 128 x 128 units.
       const int64_t pad128 = round_up(st.M, kTileM) * round_up(st.N, kTileN);
       const int64_t pad256 = round_up(st.M, 256) * round_up(st.N, kTileN);
-      if (st.modeA == 1 && st.modeB == 1 && st.tileN == kTileN && st.cvec && st.K >= 32 &&
+      const bool kcontig = st.modeA == 2 || st.modeB == 2;   // k-contiguous operands: whole k-tiles only (asm path)
+      if (st.modeA >= 1 && st.modeB >= 1 && (!kcontig || st.K % 16 == 0) && st.tileN == kTileN && st.cvec && st.K >= 32 &&
           st.M > kTileM && pad256 * 100 <= pad128 * 115 &&
           st.rhs >= 0 && P.tensors[st.lhs].numel <= (1LL << 30) && P.tensors[st.rhs].numel <= (1LL << 30))  // 32-bit byte offsets
         st.tileM = 256;

@@ -87,10 +87,10 @@ def test_random_pairwise_step_f32_larger(seed):
 
 
 def _large_tile_case(rng, dtype="float32"):
-    """Random two-operand step whose operands are both unit-stride along their free index (k labels
-    first) - the shape class of the large-tile LDS-DMA kernel.  Returns (einsum, sizes)."""
+    """Random two-operand step in the shape class of the large-tile LDS-DMA kernels: every operand unit-stride
+    along its free labels or along k.  Returns (einsum, sizes)."""
     from contractn_amd import einsum as E
-    for _ in range(200):
+    for _ in range(5000):
         nm, nn, nk = int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 3))
         m_l, n_l, k_l = list("ab"[:nm]), list("cd"[:nn]), list("ef"[:nk])
         batch = ["x"] if rng.random() < 0.3 else []
@@ -99,8 +99,9 @@ def _large_tile_case(rng, dtype="float32"):
         sizes.update({l: int(rng.choice([2, 3])) for l in batch})
         ka, kb = list(k_l), list(k_l)
         rng.shuffle(ka); rng.shuffle(kb)
-        ta = "".join(batch + ka + m_l)
-        tb = "".join(batch + kb + n_l)
+        # each operand either unit-stride along its free labels (k first) or along k (k last, fp32 only)
+        ta = "".join(batch + (ka + m_l if rng.random() < 0.5 or dtype != "float32" else m_l + ka))
+        tb = "".join(batch + (kb + n_l if rng.random() < 0.5 or dtype != "float32" else n_l + kb))
         out_m = list(m_l); rng.shuffle(out_m)                   # row labels of C in any order
         einstr = f"{ta},{tb}->{''.join(batch + out_m + n_l)}"
         shapes = tuple(tuple(sizes[c] for c in t) for t in (ta, tb))
@@ -111,7 +112,7 @@ def _large_tile_case(rng, dtype="float32"):
     raise AssertionError("no eligible case generated")
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_large_tile_steps_f32(seed, monkeypatch):
     from contractn_amd import einsum as E
     monkeypatch.setenv("CTN_MFMA_G", "2")       # take the large-tile kernel whenever the planner allows it

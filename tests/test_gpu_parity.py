@@ -266,6 +266,11 @@ def force_large_tiles(monkeypatch):
     ("km,kn->mn", [(33, 256), (33, 128)], None),                    # ragged K: 1 valid row in the last k-tile
     ("km,kn->mn", [(100, 256), (100, 256)], None),                  # K = 6 k-tiles + 4
     ("kam,kbn->ambn", [(47, 4, 100), (47, 2, 100)], None),          # everything ragged at once
+    ("mk,kn->mn", [(256, 32), (32, 128)], None),                    # row-major A (k-contiguous): requests along k
+    ("km,nk->mn", [(48, 512), (384, 48)], None),                    # k-contiguous B
+    ("mk,nk->mn", [(400, 64), (200, 64)], None),                    # both, ragged M and N
+    ("amk,kbn->ambn", [(4, 100, 32), (32, 2, 100)], None),          # composite rows over a k-contiguous A
+    ("xmk,xkn->xmn", [(2, 256, 272), (2, 272, 128)], None),         # batch + 17 k-tiles
 ])
 def test_large_tile_dma_kernel_vs_numpy(einstr, shapes, path, force_large_tiles):
     rng = np.random.default_rng(7)
