@@ -337,7 +337,11 @@ static int exec_launch_all(Exec* E) {
             used_tile(128, 128);
             a.tiles_n = (int32_t)((st.N + DN - 1) / DN);
             a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
-            hipLaunchKernelGGL(k_mfma_f64_g, dim3((unsigned)gtiles), dim3(256), 0, E->stream, a);
+            const dim3 gg((unsigned)gtiles);
+            if (st.modeA == 2 && st.modeB == 2) hipLaunchKernelGGL((k_mfma_f64_g<2, 2>), gg, dim3(256), 0, E->stream, a);
+            else if (st.modeA == 2) hipLaunchKernelGGL((k_mfma_f64_g<2, 1>), gg, dim3(256), 0, E->stream, a);
+            else if (st.modeB == 2) hipLaunchKernelGGL((k_mfma_f64_g<1, 2>), gg, dim3(256), 0, E->stream, a);
+            else hipLaunchKernelGGL((k_mfma_f64_g<1, 1>), gg, dim3(256), 0, E->stream, a);
             break;
           }
         }

@@ -30,11 +30,17 @@ __device__ __forceinline__ void glds16d(const double* g, double* lds) {
   __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds, 16, 0, 0);
 }
 
+// MA / MB = 2: the operand is unit-stride along k (a row-major A): requests along k (one lane = one row, 2
+// consecutive k), LDS image [k / 2][rows][2] with the four chunks 260 doubles apart, and BOTH operands read in
+// the permuted k order k(ks, q) = 2 q + ks (q = lane / 16), which puts a lane's two k-steps into one chunk.
+template <int MA = 1, int MB = 1>
 __global__ __launch_bounds__(256, 2) void k_mfma_f64_g(StepArgs a) {
+  constexpr bool PERM = MA == 2 || MB == 2;
+  constexpr int DCH = 260;   // doubles between the k-chunks of a k-contiguous operand's image (256 + 4 pad)
   // ONE LDS object: [stage 0 A|B][stage 1 A|B][stage 2 A|B][red 4 doubles]
-  __shared__ __attribute__((aligned(16))) double smem[DST * D_STG + 4 + 64];
+  __shared__ __attribute__((aligned(16))) double smem[DST * D_STG + 4 + 128];
   double* red = smem + DST * D_STG;
-  double* zeros = red + 4;   // 64 zeros: where the fragment reads of k-rows beyond a ragged K are pointed
+  double* zeros = red + 4;   // 128 zeros: where the fragment reads of k-rows beyond a ragged K are pointed
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -57,13 +63,22 @@ __global__ __launch_bounds__(256, 2) void k_mfma_f64_g(StepArgs a) {
 
   const int l15 = lane & 15, q = lane >> 4;
   const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
-  if (tid < 64) zeros[tid] = 0.0;   // published by the first barrier
+  if (tid < 128) zeros[tid] = 0.0;   // published by the first barrier
 
   // loader: wave w fills k-rows 2w, 2w+1 of both operand tiles; lane l brings rows / columns 2l, 2l+1.
   // (wave-uniform 64-bit base) + (per-lane unsigned 32-bit byte offset): scalar-base loads
   uint32_t offA = (uint32_t)a.omA[m0 + 2 * lane] * 8u;
   uint32_t offB = (uint32_t)a.onB[n0 + 2 * lane] * 8u;
   asm volatile("" : "+v"(offA), "+v"(offB));   // consumed before the first request (see k_mfma_f32_g)
+  uint32_t offA2[2] = {0, 0}, offB2[2] = {0, 0};   // k-contiguous operand: lane = row / column 64 g + lane
+  if constexpr (MA == 2) {
+    offA2[0] = (uint32_t)a.omA[m0 + lane] * 8u; offA2[1] = (uint32_t)a.omA[m0 + 64 + lane] * 8u;
+    asm volatile("" : "+v"(offA2[0]), "+v"(offA2[1]));
+  }
+  if constexpr (MB == 2) {
+    offB2[0] = (uint32_t)a.onB[n0 + lane] * 8u; offB2[1] = (uint32_t)a.onB[n0 + 64 + lane] * 8u;
+    asm volatile("" : "+v"(offB2[0]), "+v"(offB2[1]));
+  }
   const char* const Ac = reinterpret_cast<const char*>(A);
   const char* const Bc = reinterpret_cast<const char*>(B);
   const_i32_ptr okA = (const_i32_ptr)(a.okA + 2 * w);
@@ -81,10 +96,28 @@ __global__ __launch_bounds__(256, 2) void k_mfma_f64_g(StepArgs a) {
     double* sb = sa + D_SZ;
     uint32_t oA = offA, oB = offB;
     asm volatile("" : "+v"(oA), "+v"(oB));
+    if constexpr (MA == 2) {   // wave w brings k-chunk w (k = 2w, 2w+1) of all 128 rows: 2 requests of 64 rows
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16d(reinterpret_cast<const double*>(Ac + (int64_t)ka[i] * 8 + oA), sa + i * DROW);
+      for (int g = 0; g < 2; ++g) {
+        uint32_t o = offA2[g];
+        asm volatile("" : "+v"(o));
+        glds16d(reinterpret_cast<const double*>(Ac + (int64_t)ka[0] * 8 + o), smem + stage * D_STG + w * DCH + 128 * g);
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16d(reinterpret_cast<const double*>(Bc + (int64_t)kb[i] * 8 + oB), sb + i * DROW);
+      for (int i = 0; i < 2; ++i) glds16d(reinterpret_cast<const double*>(Ac + (int64_t)ka[i] * 8 + oA), sa + i * DROW);
+    }
+    if constexpr (MB == 2) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        uint32_t o = offB2[g];
+        asm volatile("" : "+v"(o));
+        glds16d(reinterpret_cast<const double*>(Bc + (int64_t)kb[0] * 8 + o), smem + stage * D_STG + D_SZ + w * DCH + 128 * g);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16d(reinterpret_cast<const double*>(Bc + (int64_t)kb[i] * 8 + oB), sb + i * DROW);
+    }
     const int k0 = kt_next * DK;  // the tables are padded past K
 #pragma unroll
     for (int i = 0; i < 2; ++i) { ka[i] = okA[k0 + i]; kb[i] = okB[k0 + i]; }
@@ -112,16 +145,23 @@ __global__ __launch_bounds__(256, 2) void k_mfma_f64_g(StepArgs a) {
   __builtin_amdgcn_s_waitcnt(0x0F78);              // vmcnt(8): k-tile 0 landed; k-tile 1 (4) + >= 4 table loads may be out
   __builtin_amdgcn_s_barrier();
 
-  const int fa0 = q * DROW + wm + l15;             // + (4 ks) * DROW + 16 i
-  const int fb0 = D_SZ + q * DROW + wn + l15;
+  // this lane's fragment base (doubles, lane group q folded in), the step to the tile's second k-step and the
+  // distance between 16-row fragment blocks, per operand layout:
+  //   [k][DROW], plain order k = 4 ks + q      : q DROW + row,     + 4 DROW, 16
+  //   [k][DROW], permuted order k = 2 q + ks   : 2 q DROW + row,   + DROW,   16
+  //   [k / 2][rows][2] (k-contiguous operand)  : q DCH + 2 row,    + 1,      32
+  const int fa0 = MA == 2 ? q * DCH + 2 * (wm + l15) : (PERM ? 2 * q : q) * DROW + wm + l15;
+  const int fb0 = D_SZ + (MB == 2 ? q * DCH + 2 * (wn + l15) : (PERM ? 2 * q : q) * DROW + wn + l15);
+  constexpr int ksA = MA == 2 ? 1 : (PERM ? DROW : 4 * DROW), ksB = MB == 2 ? 1 : (PERM ? DROW : 4 * DROW);
+  constexpr int blkA = MA == 2 ? 32 : 16, blkB = MB == 2 ? 32 : 16;
   int st_cur = 0, st_nxt = 1, st_req = 2;
   double xa[2][4], xb[2][4];
   {
     const double* c = smem;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xa[0][i] = c[fa0 + 16 * i];
+    for (int i = 0; i < 4; ++i) xa[0][i] = c[fa0 + blkA * i];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xb[0][j] = c[fb0 + 16 * j];
+    for (int j = 0; j < 4; ++j) xb[0][j] = c[fb0 + blkB * j];
   }
   for (int kt = 0; kt < nkt; ++kt) {
     const double* cur = smem + st_cur * D_STG;
@@ -135,17 +175,17 @@ __global__ __launch_bounds__(256, 2) void k_mfma_f64_g(StepArgs a) {
       // ADDRESS keeps the reads free of any wait, unlike zeroing the registers afterwards)
       const double *pa, *pb;
       if (ks == 0) {
-        pa = cur + fa0 + 4 * DROW; pb = cur + fb0 + 4 * DROW;
-        if (tail_cur && 4 + q >= krem) { pa = zeros; pb = zeros; }
+        pa = cur + fa0 + ksA; pb = cur + fb0 + ksB;
+        if (tail_cur && (PERM ? 2 * q + 1 : 4 + q) >= krem) { pa = zeros; pb = zeros; }
       } else {
         pa = nxt + fa0; pb = nxt + fb0;
-        if (tail_nxt && q >= krem) { pa = zeros; pb = zeros; }
+        if (tail_nxt && (PERM ? 2 * q : q) >= krem) { pa = zeros; pb = zeros; }
       }
       if (ks == 0 || kt + 1 < nkt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xa[nx][i] = pa[16 * i];
+        for (int i = 0; i < 4; ++i) xa[nx][i] = pa[blkA * i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xb[nx][j] = pb[16 * j];
+        for (int j = 0; j < 4; ++j) xb[nx][j] = pb[blkB * j];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)

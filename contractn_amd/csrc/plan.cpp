@@ -323,7 +323,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       st.blocks = (int)(st.Bt * ((st.M + kTile64M - 1) / kTile64M) * ((st.N + kTile64N - 1) / kTile64N));
       // 128 x 128 tiles fed by LDS-DMA (kernels_mfma_g64.h): same rule as the fp32 large-tile kernel
       // (two 8-deep k-tiles at least; blocks / partial slots stay counted in 128 x 64 units)
-      if (st.modeA == 1 && st.modeB == 1 && st.K >= 16 && st.N > kTile64N &&
+      if (st.modeA >= 1 && st.modeB >= 1 && st.K >= 16 && st.N > kTile64N &&
           round_up(st.N, 128) * 100 <= round_up(st.N, kTile64N) * 115 && st.rhs >= 0 &&
           P.tensors[st.lhs].numel <= (1LL << 29) && P.tensors[st.rhs].numel <= (1LL << 29))  // 32-bit byte offsets
         st.tileN = 128;

@@ -99,9 +99,9 @@ def _large_tile_case(rng, dtype="float32"):
         sizes.update({l: int(rng.choice([2, 3])) for l in batch})
         ka, kb = list(k_l), list(k_l)
         rng.shuffle(ka); rng.shuffle(kb)
-        # each operand either unit-stride along its free labels (k first) or along k (k last, fp32 only)
-        ta = "".join(batch + (ka + m_l if rng.random() < 0.5 or dtype != "float32" else m_l + ka))
-        tb = "".join(batch + (kb + n_l if rng.random() < 0.5 or dtype != "float32" else n_l + kb))
+        # each operand either unit-stride along its free labels (k first) or along k (k last)
+        ta = "".join(batch + (ka + m_l if rng.random() < 0.5 else m_l + ka))
+        tb = "".join(batch + (kb + n_l if rng.random() < 0.5 else n_l + kb))
         out_m = list(m_l); rng.shuffle(out_m)                   # row labels of C in any order
         einstr = f"{ta},{tb}->{''.join(batch + out_m + n_l)}"
         shapes = tuple(tuple(sizes[c] for c in t) for t in (ta, tb))

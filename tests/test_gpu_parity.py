@@ -315,6 +315,11 @@ def test_large_tile_dma_kernel_replicas_and_exact_sums(force_large_tiles):
     ("xkm,xkn->xmn", [(2, 32, 128), (2, 32, 128)], None),           # batch (hyperedge) label
     ("kam,kbn->ambn", [(24, 2, 64), (24, 2, 64)], None),            # composite free indices
     ("km,kn,nj->mj", [(64, 128), (64, 128), (128, 128)], ((0, 1), (0, 1))),  # an operand = rescaled intermediate
+    ("mk,kn->mn", [(128, 16), (16, 128)], None),                    # row-major A (k-contiguous): requests along k
+    ("km,nk->mn", [(40, 256), (256, 40)], None),                    # k-contiguous B
+    ("mk,nk->mn", [(130, 20), (250, 20)], None),                    # both, ragged M, N and K (4 valid rows in the last k-tile)
+    ("mk,kn->mn", [(128, 18), (18, 128)], None),                    # K tail of 2
+    ("xmk,xkn->xmn", [(2, 128, 72), (2, 72, 128)], None),           # batch + 9 k-tiles
 ])
 def test_large_tile_dma_kernel_f64_vs_numpy(einstr, shapes, path, force_large_tiles):
     rng = np.random.default_rng(17)
