@@ -276,8 +276,8 @@ static int exec_launch_all(Exec* E) {
         // same work over more CUs (measured: 2048^3 runs at 90 vs 56 TFLOP/s, 4096^3 at 125 vs 135)
         const int64_t gtiles = st.Bt * ((st.M + GM - 1) / GM) * a.tiles_n * R;
         static const bool no_asm = getenv("CTN_G_NO_ASM") != nullptr;   // development switch
-        const bool kcontig = st.modeA == 2 || st.modeB == 2;            // exists only as hand-scheduled blocks
-        if (use_g && st.tileM == GM && a.c_vec && (use_g >= 2 || gtiles >= 2LL * E->n_cu) && !(kcontig && no_asm)) {
+        const bool kcontig = st.modeA == 2 || st.modeB == 2;
+        if (use_g && st.tileM == GM && a.c_vec && (use_g >= 2 || gtiles >= 2LL * E->n_cu)) {
           a.tiles_m = (int32_t)((st.M + GM - 1) / GM);
           // long-K steps whose tiles are all full also exist as 256 x 256 tiles (8 waves, one workgroup per
           // CU: a third less L2 -> LDS traffic; measured K = 1024: 133.9 vs 130.3 TFLOP/s, K = 256: 116.0 vs 116.7)
@@ -303,11 +303,18 @@ static int exec_launch_all(Exec* E) {
             used_tile(256, 128);
             a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
             const dim3 gg((unsigned)((int64_t)a.blocks_per_replica * R));
-            if (st.modeA == 2 && st.modeB == 1) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, 2, 1>), gg, dim3(256), 0, E->stream, a);
-            else if (st.modeA == 1 && st.modeB == 2) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, 1, 2>), gg, dim3(256), 0, E->stream, a);
-            else if (kcontig) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, 2, 2>), gg, dim3(256), 0, E->stream, a);
-            else if (st.K % GK == 0 && !no_asm) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true>), gg, dim3(256), 0, E->stream, a);
-            else hipLaunchKernelGGL((k_mfma_f32_g<4, 2, false>), gg, dim3(256), 0, E->stream, a);
+            // hand-scheduled blocks for whole k-tiles, the C++ loop (which masks a ragged last k-tile) otherwise
+            const bool use_asm = st.K % GK == 0 && !no_asm;
+#define CTN_G_LAUNCH(AA, BB)                                                                             \
+            do {                                                                                         \
+              if (use_asm) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, AA, BB>), gg, dim3(256), 0, E->stream, a); \
+              else hipLaunchKernelGGL((k_mfma_f32_g<4, 2, false, AA, BB>), gg, dim3(256), 0, E->stream, a);        \
+            } while (0)
+            if (st.modeA == 2 && st.modeB == 1) CTN_G_LAUNCH(2, 1);
+            else if (st.modeA == 1 && st.modeB == 2) CTN_G_LAUNCH(1, 2);
+            else if (kcontig) CTN_G_LAUNCH(2, 2);
+            else CTN_G_LAUNCH(1, 1);
+#undef CTN_G_LAUNCH
           }
           break;
         }

@@ -55,7 +55,7 @@ __device__ __forceinline__ void glds16(const float* g, float* lds) {
 template <int NW, int NJ, bool ASM = false, int MA = 1, int MB = 1>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_f32_g(StepArgs a) {
   static_assert(!ASM || NJ == 2, "asm blocks exist for the 128 x 64 wave tile only");
-  static_assert((MA == 1 && MB == 1) || (ASM && NW == 4 && NJ == 2), "k-contiguous operands: <4, 2, asm> only");
+  static_assert((MA == 1 && MB == 1) || (NW == 4 && NJ == 2), "k-contiguous operands: the 256 x 128 tile only");
   constexpr bool PERM = MA == 2 || MB == 2;         // permuted k order (see the generator)
   constexpr int WNC = NW / 2;                       // waves along N (2 along M)
   constexpr int TNB = WNC * 32 * NJ;                // tile columns
@@ -298,12 +298,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
 #pragma unroll
     for (int kk = 0; kk < GK / 2; ++kk) {
       const int c = kk & 1, nx = c ^ 1;
+      // fragment offsets of k-step kk + 1 off the lane's base and the k it covers, per layout (as in the generator)
+      constexpr auto frag = [](int step, int rows, int mode) {
+        const int j = step / 4, e = step % 4;
+        return mode == 2 ? (2 * j * rows) * 4 + e : ((MA == 2 || MB == 2) ? 8 * j + e : 2 * step) * rows;
+      };
+      const int knext = PERM ? 8 * ((kk + 1) / 4) + 4 * h + (kk + 1) % 4 : 2 * (kk + 1) + h;
       if (kk + 1 < GK / 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[nx][i] = cA[(kk + 1) * 2 * GM + 32 * i];
+        for (int i = 0; i < 4; ++i) fa[nx][i] = cA[frag(kk + 1, GM, MA) + blkA * i];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) fb[nx][j] = cB[(kk + 1) * 2 * TNB + 32 * j];
-        if (tail_cur && 2 * (kk + 1) + h >= krem) {
+        for (int j = 0; j < NJ; ++j) fb[nx][j] = cB[frag(kk + 1, TNB, MB) + blkB * j];
+        if (tail_cur && knext >= krem) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) fa[nx][i] = 0.f;
 #pragma unroll
@@ -311,10 +317,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
         }
       } else if (kt + 1 < nkt) {  // first k-step of the next k-tile (published by this tile's barrier)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[nx][i] = nA[32 * i];
+        for (int i = 0; i < 4; ++i) fa[nx][i] = nA[blkA * i];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) fb[nx][j] = nB[32 * j];
-        if (tail_nxt && h >= krem) {
+        for (int j = 0; j < NJ; ++j) fb[nx][j] = nB[blkB * j];
+        if (tail_nxt && (PERM ? 4 * h : h) >= krem) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) fa[nx][i] = 0.f;
 #pragma unroll

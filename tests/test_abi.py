@@ -150,9 +150,9 @@ def test_planner_selects_large_tile_kernels():
     # ragged M / N / K are fine as long as 256-row tiles do not pad much more than 128-row ones
     assert info("km,kn->mn", [(100, 400), (100, 200)], "float32")["tile_m"] == 256
     assert info("km,kn->mn", [(100, 300), (100, 128)], "float32")["tile_m"] == 128      # 300 -> 512 rows: too much padding
-    # a k-contiguous (row-major) operand: fp32 large tiles need whole k-tiles for it, fp64 takes any K
+    # a k-contiguous (row-major) operand is fine too, with any K
     assert info("mk,kn->mn", [(256, 256), (256, 1024)], "float32")["tile_m"] == 256
-    assert info("mk,kn->mn", [(256, 40), (40, 1024)], "float32")["tile_m"] == 128
+    assert info("mk,kn->mn", [(256, 40), (40, 1024)], "float32")["tile_m"] == 256
     assert info("mk,kn->mn", [(256, 256), (256, 1024)], "float64")["tile_n"] == 128
     assert info("mk,kn->mn", [(256, 42), (42, 1024)], "float64")["tile_n"] == 128
     # fewer than two k-tiles

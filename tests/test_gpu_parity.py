@@ -271,6 +271,9 @@ def force_large_tiles(monkeypatch):
     ("mk,nk->mn", [(400, 64), (200, 64)], None),                    # both, ragged M and N
     ("amk,kbn->ambn", [(4, 100, 32), (32, 2, 100)], None),          # composite rows over a k-contiguous A
     ("xmk,xkn->xmn", [(2, 256, 272), (2, 272, 128)], None),         # batch + 17 k-tiles
+    ("mk,kn->mn", [(256, 40), (40, 128)], None),                    # row-major A with a ragged K (C++ inner loop)
+    ("mk,nk->mn", [(400, 100), (200, 100)], None),                  # both k-contiguous, K = 6 k-tiles + 4
+    ("km,nk->mn", [(36, 512), (128, 36)], None),                    # k-contiguous B, 4 valid rows in the last k-tile
 ])
 def test_large_tile_dma_kernel_vs_numpy(einstr, shapes, path, force_large_tiles):
     rng = np.random.default_rng(7)
