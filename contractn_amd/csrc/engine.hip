@@ -65,7 +65,7 @@ struct Exec {
   bool ptrs_valid = false;
   double* d_partials = nullptr;
   double* d_scratch = nullptr;
-  float* d_slab = nullptr;          // split-K partial tiles (latency mode), sized at creation
+  void* d_slab = nullptr;           // split-K partial tiles (latency mode), sized at creation
   std::vector<int> step_partials;   // abs-sum partials per replica of every step (plan value unless split-K)
   double* d_log = nullptr;
   double* d_resc = nullptr;
@@ -145,7 +145,8 @@ static void launch_mfma(int ma, int mb, int tile_n, dim3 grid, hipStream_t st, c
 // CTN_SPLITK=1 forces it for every eligible step (tests).
 static int splitk_splits(const Step& st, int R, int n_cu, int dtype) {
   static const int mode = [] { const char* e = getenv("CTN_SPLITK"); return e ? atoi(e) : -1; }();
-  if (mode == 0 || dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.collapse || st.K < 128) return 0;
+  const bool mfma = (dtype == CTN_F32 && st.kernel == CTN_KERNEL_MFMA_F32) || (dtype == CTN_F64 && st.kernel == CTN_KERNEL_MFMA_F64);
+  if (mode == 0 || !mfma || st.collapse || st.K < 128) return 0;
   static const int max_tiles = [] { const char* e = getenv("CTN_SPLITK_MAX"); return e ? atoi(e) : 0; }();
   const int64_t limit = max_tiles > 0 ? max_tiles : n_cu / 2;
   if (mode != 1 && (int64_t)st.blocks * R > limit) return 0;
@@ -169,6 +170,23 @@ static void launch_sk(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs&
     case 1: launch_sk_b<1>(mb, grid, st, a, sk); break;
     case 2: launch_sk_b<2>(mb, grid, st, a, sk); break;
     default: launch_sk_b<0>(mb, grid, st, a, sk); break;
+  }
+}
+
+template <int MA>
+static void launch_sk64_b(int mb, dim3 grid, hipStream_t st, const StepArgs& a, const SplitKArgs& sk) {
+  switch (mb) {
+    case 1: hipLaunchKernelGGL((k_mfma_f64_sk<MA, 1>), grid, dim3(256), 0, st, a, sk); break;
+    case 2: hipLaunchKernelGGL((k_mfma_f64_sk<MA, 2>), grid, dim3(256), 0, st, a, sk); break;
+    default: hipLaunchKernelGGL((k_mfma_f64_sk<MA, 0>), grid, dim3(256), 0, st, a, sk); break;
+  }
+}
+
+static void launch_sk64(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a, const SplitKArgs& sk) {
+  switch (ma) {
+    case 1: launch_sk64_b<1>(mb, grid, st, a, sk); break;
+    case 2: launch_sk64_b<2>(mb, grid, st, a, sk); break;
+    default: launch_sk64_b<0>(mb, grid, st, a, sk); break;
   }
 }
 
@@ -253,7 +271,7 @@ static int exec_launch_all(Exec* E) {
           sk.tiles_per_replica = (int32_t)(st.Bt * sk.tiles_m * sk.tiles_n);
           used_tile(64, 64);
           launch_sk(st.modeA, st.modeB, dim3((unsigned)((int64_t)sk.tiles_per_replica * sk.S * R)), E->stream, a, sk);
-          hipLaunchKernelGGL(k_splitk_reduce, dim3(E->step_partials[s], R), dim3(256), 0, E->stream, a, sk);
+          hipLaunchKernelGGL(k_splitk_reduce<float>, dim3(E->step_partials[s], R), dim3(256), 0, E->stream, a, sk);
           break;
         }
         a.tiles_n = (int32_t)((st.N + st.tileN - 1) / st.tileN);
@@ -337,6 +355,20 @@ static int exec_launch_all(Exec* E) {
       case CTN_KERNEL_MFMA_F64: {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
+        if (const int S = E->d_slab ? splitk_splits(st, R, E->n_cu, P.dtype) : 0) {   // latency mode, as in fp32
+          SplitKArgs sk;
+          sk.slab = E->d_slab;
+          sk.numelC = P.tensors[st.out].numel;
+          sk.kchunk = (int32_t)(((st.K + S - 1) / S + 31) / 32 * 32);
+          sk.S = (int32_t)((st.K + sk.kchunk - 1) / sk.kchunk);  // drop empty trailing splits
+          sk.tiles_m = (int32_t)((st.M + 63) / 64);
+          sk.tiles_n = (int32_t)((st.N + 63) / 64);
+          sk.tiles_per_replica = (int32_t)(st.Bt * sk.tiles_m * sk.tiles_n);
+          used_tile(64, 64);
+          launch_sk64(st.modeA, st.modeB, dim3((unsigned)((int64_t)sk.tiles_per_replica * sk.S * R)), E->stream, a, sk);
+          hipLaunchKernelGGL(k_splitk_reduce<double>, dim3(E->step_partials[s], R), dim3(256), 0, E->stream, a, sk);
+          break;
+        }
         a.tiles_m = (int32_t)((st.M + kTile64M - 1) / kTile64M);
         if (E->mfma_g && st.tileN == DN) {  // 128 x 128 LDS-DMA kernel, under the same launch-size rule as fp32
           const int64_t gtiles = st.Bt * a.tiles_m * ((st.N + DN - 1) / DN) * R;
@@ -587,7 +619,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     for (const Step& st : P.steps)
       if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype))
         slab_elems = std::max(slab_elems, (size_t)S * (size_t)P.tensors[st.out].numel * (size_t)replicas);
-    if (slab_elems) HIPCHECK_X(hipMalloc((void**)&E.d_slab, slab_elems * sizeof(float)));
+    if (slab_elems) HIPCHECK_X(hipMalloc((void**)&E.d_slab, slab_elems * (P.dtype == CTN_F64 ? 8 : 4)));
   }
   // partial counts: the split-K reduce pass spreads over up to 64 workgroups per replica
   E.step_partials.resize(P.n_steps);

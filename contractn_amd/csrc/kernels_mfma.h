@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
 // reproducible, no atomics), applies the lazy rescale and emits the abs-sum partials.
 // ---------------------------------------------------------------------------
 struct SplitKArgs {
-  float* slab;        // [R][S][numelC]
+  void* slab;         // [R][S][numelC] elements of the plan's dtype
   int64_t numelC;
   int32_t S, kchunk;  // splits and K elements per split (multiple of 32)
   int32_t tiles_m, tiles_n, tiles_per_replica;  // 64-wide tiles
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_mfma_f32_sk(StepArgs a, SplitKArgs sk) 
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
   const float* __restrict__ B = (const float*)tp[a.idB] + a.obB[b];
-  float* __restrict__ C = sk.slab + ((size_t)r * sk.S + s) * sk.numelC + a.obC[b];
+  float* __restrict__ C = (float*)sk.slab + ((size_t)r * sk.S + s) * sk.numelC + a.obC[b];
 
   if (tid < T) s_omC[tid] = a.omC[m0 + tid];
   else if (tid < 2 * T) s_onC[tid - T] = a.onC[n0 + tid - T];
@@ -474,35 +474,42 @@ __global__ __launch_bounds__(256) void k_mfma_f32_sk(StepArgs a, SplitKArgs sk) 
 
 // Sum the S partial slabs in order, apply the producers' rescale, write C and the abs-sum partials
 // (exactly P = the step's planned partial count of workgroups per replica, so consumers are unchanged).
+template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_reduce(StepArgs a, SplitKArgs sk) {
   __shared__ double red[4];
+  constexpr int V = 16 / sizeof(T);   // elements per 16-byte vector
   const int r = blockIdx.y;
-  const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
-  const float iA = 1.0f / scA, iB = 1.0f / scB;
-  float* __restrict__ C = (float*)a.ptrs[(size_t)r * a.n_tensors + a.idC];
-  const float* __restrict__ slab = sk.slab + (size_t)r * sk.S * sk.numelC;
+  const T scA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const T scB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const T iA = (T)1 / scA, iB = (T)1 / scB;
+  T* __restrict__ C = (T*)a.ptrs[(size_t)r * a.n_tensors + a.idC];
+  const T* __restrict__ slab = (const T*)sk.slab + (size_t)r * sk.S * sk.numelC;
   const int64_t per = ((sk.numelC + gridDim.x - 1) / gridDim.x + 3) & ~(int64_t)3;  // multiple of 4
   const int64_t lo = (int64_t)blockIdx.x * per, hi = min(sk.numelC, lo + per);
-  float asum = 0.f;
+  T asum = 0;
   if ((sk.numelC & 3) == 0) {  // 16-byte vectors (slabs and C are 256-byte aligned)
-    for (int64_t i = lo + threadIdx.x * 4; i < hi; i += 1024) {
-      float4 v = *reinterpret_cast<const float4*>(slab + i);
+    for (int64_t i = lo + threadIdx.x * V; i < hi; i += 256 * V) {
+      T v[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = slab[i + e];
       for (int s = 1; s < sk.S; ++s) {
-        const float4 x = *reinterpret_cast<const float4*>(slab + (size_t)s * sk.numelC + i);
-        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] += slab[(size_t)s * sk.numelC + i + e];
       }
-      v.x = (v.x * iA) * iB; v.y = (v.y * iA) * iB; v.z = (v.z * iA) * iB; v.w = (v.w * iA) * iB;
-      *reinterpret_cast<float4*>(C + i) = v;
-      asum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+#pragma unroll
+      for (int e = 0; e < V; ++e) { v[e] = (v[e] * iA) * iB; C[i + e] = v[e]; }
+      T part = 0;
+#pragma unroll
+      for (int e = 0; e < V; ++e) part += fabs(v[e]);
+      asum += part;
     }
   } else {
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-      float v = slab[i];
+      T v = slab[i];
       for (int s = 1; s < sk.S; ++s) v += slab[(size_t)s * sk.numelC + i];
       v = (v * iA) * iB;
       C[i] = v;
-      asum += fabsf(v);
+      asum += fabs(v);
     }
   }
   const double tot = block_sum((double)asum, red);
@@ -738,5 +745,128 @@ __global__ __launch_bounds__(256, 2) void k_mfma_f64(StepArgs a) {
   if (tid == 0) a.partC[(size_t)r * a.partC_stride + t] = tot;
 }
 
+
+
+// ---------------------------------------------------------------------------
+// K-mfma-f64-sk: the latency mode in fp64 (the dtype a NumPy user's single network arrives in): 64x64
+// tiles, 4 waves of 32x32 = 2x2 v_mfma_f64_16x16x4_f64 accumulators, BK = 16, K split S ways; partial
+// tiles go to slab s, k_splitk_reduce<double> sums them in a fixed order.
+// ---------------------------------------------------------------------------
+template <int MA, int MB>
+__global__ __launch_bounds__(256) void k_mfma_f64_sk(StepArgs a, SplitKArgs sk) {
+  constexpr int T = 64, BK = 16, LD = 80;
+  using LA = TileLoaderD<MA, T, LD>;
+  using LB = TileLoaderD<MB, T, LD>;
+  constexpr int SZA = LA::kSize, SZB = LB::kSize;
+  __shared__ __attribute__((aligned(16))) double smem[2 * SZA + 2 * SZB];
+  __shared__ int s_omC[T], s_onC[T];
+  double* sA = smem;
+  double* sB = smem + 2 * SZA;
+
+  const int tid = threadIdx.x;
+  const int per_rep = sk.tiles_per_replica * sk.S;
+  const int pid = blockIdx.x;
+  const int r = pid / per_rep;
+  const int rem = pid - r * per_rep;
+  const int t = rem / sk.S;
+  const int s = rem - t * sk.S;
+  const int tiles_mn = sk.tiles_m * sk.tiles_n;
+  const int b = t / tiles_mn;
+  const int tt = t - b * tiles_mn;
+  const int m0 = (tt / sk.tiles_n) * T;
+  const int n0 = (tt % sk.tiles_n) * T;
+  const int kbeg = s * sk.kchunk;
+  const int kend = min(a.K, kbeg + sk.kchunk);
+
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const double* __restrict__ A = (const double*)tp[a.idA] + a.obA[b];
+  const double* __restrict__ B = (const double*)tp[a.idB] + a.obB[b];
+  double* __restrict__ C = (double*)sk.slab + ((size_t)r * sk.S + s) * sk.numelC + a.obC[b];
+
+  if (tid < T) s_omC[tid] = a.omC[m0 + tid];
+  else if (tid < 2 * T) s_onC[tid - T] = a.onC[n0 + tid - T];
+
+  LA la;
+  LB lb;
+  la.init(a.omA, m0, a.M, tid);
+  lb.init(a.onB, n0, a.N, tid);
+
+  const int lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+  const int l15 = lane & 15, q = lane >> 4;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+
+  const int nkt = (kend - kbeg + BK - 1) / BK;   // >= 1 (host guarantees kbeg < K)
+  la.tab(a.okA, kbeg, tid);
+  lb.tab(a.okB, kbeg, tid);
+  la.load(A);
+  lb.load(B);
+  la.tab(a.okA, kbeg + BK, tid);
+  lb.tab(a.okB, kbeg + BK, tid);
+  la.store(sA, kbeg, kend, tid);
+  lb.store(sB, kbeg, kend, tid);
+  __syncthreads();
+
+  const int fa = q * LD + wm + l15, fb = q * LD + wn + l15;  // + (4 kk) * LD + 16 * block
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      la.load(A);
+      lb.load(B);
+      la.tab(a.okA, kbeg + (kt + 2) * BK, tid);
+      lb.tab(a.okB, kbeg + (kt + 2) * BK, tid);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const double* cA = sA + cur * SZA;
+    const double* cB = sB + cur * SZB;
+    double xa[2][2], xb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { xa[0][i] = cA[fa + 16 * i]; xb[0][i] = cB[fb + 16 * i]; }
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int c = kk & 1, nx = c ^ 1;
+      if (kk + 1 < BK / 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          xa[nx][i] = cA[fa + (kk + 1) * 4 * LD + 16 * i];
+          xb[nx][i] = cB[fb + (kk + 1) * 4 * LD + 16 * i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][i], xb[c][j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      la.store(sA + (cur ^ 1) * SZA, kbeg + (kt + 1) * BK, kend, tid);
+      lb.store(sB + (cur ^ 1) * SZB, kbeg + (kt + 1) * BK, kend, tid);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = wn + 16 * j + l15;
+    if (n0 + col < a.N) {
+      const int offn = s_onC[col];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = wm + 16 * i + q + 4 * e;
+          if (m0 + row < a.M) C[s_omC[row] + offn] = acc[i][j][e];
+        }
+    }
+  }
+}
 
 }  // namespace ctn

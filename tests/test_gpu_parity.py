@@ -356,3 +356,26 @@ def test_launcher_retiles_by_replica_count():
             assert np.max(np.abs(got - ref)) <= 2e-5 * np.max(np.abs(ref)) * 10
         assert np.array_equal(t[0], t[replicas - 1])
         bc.executor.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-12)])
+@pytest.mark.parametrize("einstr,shapes", [
+    ("km,kn->mn", [(300, 70), (300, 100)]),             # ragged 64-tiles, 10 k-tiles of 32 minus a bit
+    ("mk,kn->mn", [(256, 1024), (1024, 256)]),          # the MPS environment step, row-major A
+    ("mk,nk->mn", [(130, 200), (90, 200)]),             # both k-contiguous
+    ("xkm,xkn->xmn", [(2, 160, 64), (2, 160, 96)]),     # batch label
+])
+def test_latency_mode_split_k(dtype, tol, einstr, shapes):
+    """One small network: 64 x 64 tiles with K split over workgroups and a fixed-order slab reduction,
+    in fp32 and in fp64 (ctn_exec_step_tile reports the 64 x 64 kernel)."""
+    rng = np.random.default_rng(5)
+    ops = [rng.standard_normal(s).astype(dtype) for s in shapes]
+    bc = E.BatchedContraction(einstr, shapes, dtype, optimize=((0, 1),), replicas=1)
+    t, c = bc.run_host([ops])
+    assert bc.executor.step_tiles() == [(64, 64)]
+    bc.executor.close()
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    got = t[0].astype(np.float64) * np.exp(float(c[0]))
+    assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)) * 10
+    t2, c2 = contract(einstr, *ops, split_format=True)      # bit-reproducible: same reduction order every time
+    assert np.array_equal(t2, t[0]) and float(c2) == float(c[0])
