@@ -58,7 +58,8 @@ typedef enum {
   CTN_KERNEL_MFMA_F32 = 2,/* 128x128 / 128x64 LDS-tiled v_mfma_f32_32x32x2_f32 GEMM, gather loads;
                              256x128 tiles fed by LDS-DMA when every tile is full (tile_m = 256);
                              64x64 split-K form when a launch cannot fill the chip */
-  CTN_KERNEL_MFMA_F64 = 3,/* 128x64 LDS-tiled v_mfma_f64_16x16x4_f64 GEMM, gather loads */
+  CTN_KERNEL_MFMA_F64 = 3,/* 128x64 LDS-tiled v_mfma_f64_16x16x4_f64 GEMM, gather loads; 128x128 tiles fed by
+                             LDS-DMA (tile_n = 128); 64x64 split-K form for small launches */
   CTN_KERNEL_ROWDOT = 4   /* one wave per output element, lanes along a unit-stride K (GEMV-like) */
 } ctn_kernel_kind;
 
