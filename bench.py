@@ -253,7 +253,7 @@ def kernel_label(key):
 
     kind, ma, mb, tm, tn = key
     if kind == 2 and tm == 256:
-        return f"k_mfma_f32_g<{'8' if tn == 256 else '4'},2,asm> ({tm}x{tn} tiles, LDS-DMA ring)"
+        return f"k_mfma_f32_g<{'8' if tn == 256 else '4'},2,asm,{ma},{mb}> ({tm}x{tn} tiles, LDS-DMA ring)"
     if kind == 3 and tn == 128:
         return "k_mfma_f64_g (128x128 tiles, LDS-DMA ring)"
     if kind in (2, 3) and tm:
