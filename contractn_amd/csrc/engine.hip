@@ -295,7 +295,9 @@ static int exec_launch_all(Exec* E) {
         const int64_t gtiles = st.Bt * ((st.M + GM - 1) / GM) * a.tiles_n * R;
         static const bool no_asm = getenv("CTN_G_NO_ASM") != nullptr;   // development switch
         const bool kcontig = st.modeA == 2 || st.modeB == 2;
-        if (use_g && st.tileM == GM && a.c_vec && (use_g >= 2 || gtiles >= 2LL * E->n_cu)) {
+        // ... and K >= 192: below that the 128-tile kernel's 3-4 workgroups per CU hide the per-tile cost
+        // better (8192 x 8192 x K: K = 64 old +7 %, 128 +2 %, 192 equal, 256 large tiles +5 %)
+        if (use_g && st.tileM == GM && a.c_vec && (use_g >= 2 || (gtiles >= 2LL * E->n_cu && st.K >= 192))) {
           a.tiles_m = (int32_t)((st.M + GM - 1) / GM);
           // long-K steps whose tiles are all full also exist as 256 x 256 tiles (8 waves, one workgroup per
           // CU: a third less L2 -> LDS traffic; measured K = 1024: 133.9 vs 130.3 TFLOP/s, K = 256: 116.0 vs 116.7)
