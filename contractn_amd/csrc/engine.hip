@@ -299,10 +299,13 @@ static int exec_launch_all(Exec* E) {
         // better (8192 x 8192 x K: K = 64 old +7 %, 128 +2 %, 192 equal, 256 large tiles +5 %)
         if (use_g && st.tileM == GM && a.c_vec && (use_g >= 2 || (gtiles >= 2LL * E->n_cu && st.K >= 192))) {
           a.tiles_m = (int32_t)((st.M + GM - 1) / GM);
-          // long-K steps whose tiles are all full also exist as 256 x 256 tiles (8 waves, one workgroup per
-          // CU: a third less L2 -> LDS traffic; measured K = 1024: 133.9 vs 130.3 TFLOP/s, K = 256: 116.0 vs 116.7)
-          const bool big = use_g == 1 && !kcontig && st.M % 256 == 0 && st.N % 256 == 0 && st.K % GK == 0 && st.K >= 512 &&
-                           gtiles / 2 >= (int64_t)E->n_cu;
+          // long-K steps on narrow outputs whose tiles are all full also exist as 256 x 256 tiles (8 waves, one
+          // workgroup per CU): with N <= 512 each A tile is fetched half as often (256 x 256 x 1024 per replica:
+          // 133.9 vs 130.3 TFLOP/s); K = 256 steps (116.0 vs 116.7) and wide outputs (8192 x 8192 x 768: 130.3 vs
+          // 132.1) are better off with 256 x 128
+          // - and so are very long K on any width (K = 2048 ... 8192: +1.5 ... +3 %)
+          const bool big = use_g == 1 && !kcontig && st.M % 256 == 0 && st.N % 256 == 0 && st.K % GK == 0 &&
+                           ((st.K >= 512 && st.N <= 512) || st.K >= 1536) && gtiles / 2 >= (int64_t)E->n_cu;
           if (big) {
             used_tile(256, 256);
             a.tiles_n = (int32_t)(st.N / 256);
