@@ -213,7 +213,8 @@ def main():
     }
 
     result = {
-        "metric": f"contractions/sec (MPS-100 overlap, bond=256, phys=4, {'fp64' if f64 else 'fp32'}, stabilised split format)",
+        "metric": (f"contractions/sec (MPS-{args.sites} overlap, bond={args.bond}, phys={args.phys}, "
+                   f"{'fp64' if f64 else 'fp32'}, stabilised split format)"),
         "value": round(value, 2),
         "unit": "contractions/s",
         "n_gpus": world,
