@@ -236,6 +236,7 @@ def main():
         },
         "achieved_tflops": round(tflops, 3),
         "roofline": roofline,
+        "device": device_info(dev),
     }
 
     # ---- CPU baseline: the oracle on the same network and path (rank 0, N=1 only) --------
@@ -246,6 +247,29 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def device_info(dev):
+    """Name, CU count and clocks of the card the numbers were taken on (print them with
+    every result).  ``sclk_now_mhz`` is the active level in the driver's sysfs table, best effort."""
+    import torch
+
+    props = torch.cuda.get_device_properties(dev)
+    info = {"name": props.name, "arch": getattr(props, "gcnArchName", None),
+            "compute_units": props.multi_processor_count,
+            "max_clock_mhz": round(getattr(props, "clock_rate", 0) / 1e3, 1) or None,
+            "hbm_gib": round(props.total_memory / 2**30, 1)}
+    try:
+        import glob
+
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            active = [ln for ln in open(f).read().splitlines() if ln.strip().endswith("*")]
+            if active:
+                info["sclk_now_mhz"] = int("".join(ch for ch in active[0].split(":")[1] if ch.isdigit()))
+                break
+    except Exception:
+        pass
+    return info
 
 
 def kernel_label(key):

@@ -7,8 +7,8 @@ contractn/__init__.py); ``BatchedContraction`` (R networks per launch sequence) 
 from . import engine  # noqa: F401  (ctypes binding of the C ABI; no GPU needed to import)
 from .ctn import TN
 from .edges import Edge
-from .einsum import BatchedContraction, clear_caches, contract
+from .einsum import BatchedContraction, clear_caches, contract, destabilize, stabilize
 from .nodes import Node
 
 __version__ = "0.1.0"
-__all__ = ["TN", "Node", "Edge", "contract", "BatchedContraction", "clear_caches", "engine", "__version__"]
+__all__ = ["TN", "Node", "Edge", "contract", "stabilize", "destabilize", "BatchedContraction", "clear_caches", "engine", "__version__"]

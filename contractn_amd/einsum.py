@@ -178,6 +178,22 @@ def accumulate_log_scale(step_rescales, dtype):
     return np.asarray(np.add.accumulate(logs)[-1])  # strictly sequential adds
 
 
+def stabilize(tensor, log_scale, backend="auto"):
+    """Move the mean magnitude of ``tensor`` into the ``log_scale`` register and return both
+    (reference einsum.py:89-107): ``(tensor / s, log_scale + log s)`` with ``s = sum|tensor| / numel``
+    when ``sum|tensor| > 1e-7``, otherwise both unchanged.
+
+    Runs on the device as a one-operand plan (the same abs-sum / rescale / finalize kernels every
+    pairwise step ends with), so like ``contract`` it raises without the HIP library or a GPU.
+    """
+    ndim = len(tensor.shape)
+    if ndim > 52:
+        raise ValueError("stabilize: more than 52 axes")
+    sub = "".join(chr(ord("a") + i) if i < 26 else chr(ord("A") + i - 26) for i in range(ndim))
+    t_hat, c = contract(sub + "->" + sub, tensor, split_format=True, backend=backend)
+    return t_hat, log_scale + c
+
+
 def destabilize(tensor, log_scale, backend="numpy"):
     """``tensor * exp(log_scale)`` (reference einsum.py:110-114); may overflow to inf by design."""
     if backend == "torch":

@@ -379,3 +379,31 @@ def test_latency_mode_split_k(dtype, tol, einstr, shapes):
     assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)) * 10
     t2, c2 = contract(einstr, *ops, split_format=True)      # bit-reproducible: same reduction order every time
     assert np.array_equal(t2, t[0]) and float(c2) == float(c[0])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(), (7,), (33, 65), (4, 3, 5, 2), (1024, 1024)])
+def test_stabilize_function(shape, dtype):
+    """The stand-alone ``stabilize`` (reference einsum.py:89-107): rescaled tensor, register update,
+    exact-sum cases bit for bit, and the "norm below 1e-7 leaves both unchanged" branch."""
+    from oracle import cpu_ref
+
+    rng = np.random.default_rng(len(shape) + 17)
+    t = np.asarray(rng.standard_normal(shape) * 37.5).astype(dtype)
+    c0 = np.asarray(2.5)
+    got_t, got_c = E.stabilize(t, c0)
+    ref_t, ref_c = cpu_ref.stabilize(t, c0)
+    assert got_t.shape == t.shape and got_t.dtype == t.dtype
+    assert rel_err(got_t, ref_t) <= TIGHT[np.dtype(dtype)]
+    assert abs(float(got_c) - float(ref_c)) <= (1e-12 if dtype == np.float64 else 2e-6) * abs(float(ref_c))
+
+    ones = np.full(shape, 8.0, dtype=dtype)  # power-of-two values: every abs-sum is exact
+    got_t, got_c = E.stabilize(ones, np.asarray(0.0))
+    ref_t, ref_c = cpu_ref.stabilize(ones, np.asarray(0.0))
+    np.testing.assert_array_equal(got_t, ref_t)
+    assert float(got_c).hex() == float(ref_c).hex()
+
+    tiny = np.full(shape, 1e-12, dtype=dtype) if np.prod(shape, dtype=np.int64) * 1e-12 < 1e-7 else np.zeros(shape, dtype)
+    got_t, got_c = E.stabilize(tiny, np.asarray(1.25))
+    np.testing.assert_array_equal(got_t, tiny)
+    assert float(got_c) == 1.25
