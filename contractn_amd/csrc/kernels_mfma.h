@@ -474,10 +474,49 @@ __global__ __launch_bounds__(256) void k_mfma_f32_sk(StepArgs a, SplitKArgs sk) 
 
 // Sum the S partial slabs in order, apply the producers' rescale, write C and the abs-sum partials
 // (exactly P = the step's planned partial count of workgroups per replica, so consumers are unchanged).
+// The pass is pure latency (a few MB from L2): a thread's SMAX x U 16-byte loads - every slab of U
+// vectors - are all requested before the first add, one round trip instead of S x iterations of them;
+// the adds stay in slab order.
+template <typename T, int SMAX, int U>
+__device__ __forceinline__ T splitk_reduce_span(const T* __restrict__ slab, T* __restrict__ C, int64_t numelC, int S,
+                                                int64_t lo, int64_t hi, T iA, T iB) {
+  constexpr int V = 16 / sizeof(T);
+  struct alignas(16) Vec { T x[V]; };
+  T asum = 0;
+  for (int64_t i0 = lo + (int64_t)threadIdx.x * V; i0 < hi; i0 += (int64_t)256 * V * U) {
+    Vec x[SMAX][U];
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + (int64_t)u * 256 * V;
+        if (s < S && i < hi) x[s][u] = *reinterpret_cast<const Vec*>(slab + (size_t)s * numelC + i);
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * 256 * V;
+      if (i < hi) {
+        Vec v = x[0][u];
+#pragma unroll
+        for (int s = 1; s < SMAX; ++s)
+          if (s < S) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) v.x[e] += x[s][u].x[e];
+          }
+        T part = 0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { v.x[e] = (v.x[e] * iA) * iB; part += fabs(v.x[e]); }
+        *reinterpret_cast<Vec*>(C + i) = v;
+        asum += part;
+      }
+    }
+  }
+  return asum;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_reduce(StepArgs a, SplitKArgs sk) {
   __shared__ double red[4];
-  constexpr int V = 16 / sizeof(T);   // elements per 16-byte vector
   const int r = blockIdx.y;
   const T scA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
   const T scB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
@@ -487,22 +526,10 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(StepArgs a, SplitKArgs sk
   const int64_t per = ((sk.numelC + gridDim.x - 1) / gridDim.x + 3) & ~(int64_t)3;  // multiple of 4
   const int64_t lo = (int64_t)blockIdx.x * per, hi = min(sk.numelC, lo + per);
   T asum = 0;
-  if ((sk.numelC & 3) == 0) {  // 16-byte vectors (slabs and C are 256-byte aligned)
-    for (int64_t i = lo + threadIdx.x * V; i < hi; i += 256 * V) {
-      T v[V];
-#pragma unroll
-      for (int e = 0; e < V; ++e) v[e] = slab[i + e];
-      for (int s = 1; s < sk.S; ++s) {
-#pragma unroll
-        for (int e = 0; e < V; ++e) v[e] += slab[(size_t)s * sk.numelC + i + e];
-      }
-#pragma unroll
-      for (int e = 0; e < V; ++e) { v[e] = (v[e] * iA) * iB; C[i + e] = v[e]; }
-      T part = 0;
-#pragma unroll
-      for (int e = 0; e < V; ++e) part += fabs(v[e]);
-      asum += part;
-    }
+  if ((sk.numelC & 3) == 0 && sk.S <= 16) {  // 16-byte vectors (slabs and C are 256-byte aligned)
+    if (sk.S <= 4) asum = splitk_reduce_span<T, 4, 4>(slab, C, sk.numelC, sk.S, lo, hi, iA, iB);
+    else if (sk.S <= 8) asum = splitk_reduce_span<T, 8, 2>(slab, C, sk.numelC, sk.S, lo, hi, iA, iB);
+    else asum = splitk_reduce_span<T, 16, 1>(slab, C, sk.numelC, sk.S, lo, hi, iA, iB);
   } else {
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
       T v = slab[i];
