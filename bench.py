@@ -263,9 +263,12 @@ def device_info(dev):
         import glob
 
         for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
-            active = [ln for ln in open(f).read().splitlines() if ln.strip().endswith("*")]
+            levels = open(f).read().splitlines()
+            mhz = lambda ln: int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))  # noqa: E731
+            active = [ln for ln in levels if ln.strip().endswith("*")]
             if active:
-                info["sclk_now_mhz"] = int("".join(ch for ch in active[0].split(":")[1] if ch.isdigit()))
+                info["sclk_now_mhz"] = mhz(active[0])
+                info["max_clock_mhz"] = info["max_clock_mhz"] or max(mhz(ln) for ln in levels if ":" in ln)
                 break
     except Exception:
         pass

@@ -364,6 +364,9 @@ def test_launcher_retiles_by_replica_count():
     ("mk,kn->mn", [(256, 1024), (1024, 256)]),          # the MPS environment step, row-major A
     ("mk,nk->mn", [(130, 200), (90, 200)]),             # both k-contiguous
     ("xkm,xkn->xmn", [(2, 160, 64), (2, 160, 96)]),     # batch label
+    ("km,kn->mn", [(512, 128), (512, 128)]),            # 8 slabs (the reduce pass's 8 x 2 form)
+    ("km,kn->mn", [(2304, 64), (2304, 64)]),            # 36 slabs: more than the unrolled forms take
+    ("km,kn->mn", [(256, 65), (256, 33)]),              # odd element count: scalar reduce path
 ])
 def test_latency_mode_split_k(dtype, tol, einstr, shapes):
     """One small network: 64 x 64 tiles with K split over workgroups and a fixed-order slab reduction,
