@@ -56,7 +56,13 @@ struct Exec {
   int R = 1;
   int n_tensors = 0;
   int n_cu = 256;
-  int mfma_g = 1;        // CTN_MFMA_G at creation time (see exec_launch_all)
+  int mfma_g = 1;        // CTN_MFMA_G at creation time (see exec_launch_steps)
+  // the launch sequence as a hipGraph (CTN_GRAPH, see exec_launch_all): captured on the second enqueue,
+  // replayed afterwards; tensors are reached through the device pointer table, so new operands need no update
+  int use_graph = 1;
+  bool graph_warm = false;          // one eager enqueue has run (code objects loaded, tiles recorded)
+  bool graph_aligned = true;        // outs_aligned16 the graph was captured under
+  hipGraphExec_t graph_exec = nullptr;
   std::vector<int32_t> launched_tile;  // per step: (tile rows << 16 | tile columns) of the last enqueue's MFMA kernel, else 0
   char* d_ws = nullptr;
   int32_t* d_tables = nullptr;
@@ -93,6 +99,7 @@ struct Exec {
       if (p) (void)hipFree(p);
     if (h_pack) (void)hipHostFree(h_pack);
     for (auto ev : events) (void)hipEventDestroy(ev);
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -190,7 +197,7 @@ static void launch_sk64(int ma, int mb, dim3 grid, hipStream_t st, const StepArg
   }
 }
 
-static int exec_launch_all(Exec* E) {
+static int exec_launch_steps(Exec* E) {
   const Plan& P = *E->plan;
   const int R = E->R;
   const bool chain = P.chain && E->d_chain != nullptr;
@@ -461,6 +468,51 @@ static int exec_launch_all(Exec* E) {
   return CTN_OK;
 }
 
+// One enqueue of the whole path.  A path is hundreds of launches whose arguments never change (operands are
+// reached through the device pointer table), and with one small or mid-size network in flight the host's
+// launch rate, not the device, bounds the walk (100-site MPS, D = 32 ... 256: 1.3 - 2.3 ms of enqueue for
+// 1.6 - 2.6 ms of wall time): from the third enqueue on the sequence is replayed as ONE hipGraph launch.
+// Event-timed enqueues, the single-launch chain walk, debug stamping and streams that are themselves being
+// captured stay eager.  CTN_GRAPH=0 disables.
+static int exec_launch_all(Exec* E) {
+  const Plan& P = *E->plan;
+  const bool timed = E->timing_runs < E->timing_slots;
+  const bool chain = P.chain && E->d_chain != nullptr;
+  if (!E->use_graph || timed || chain || P.n_steps < 4 || getenv("CTN_DEBUG_STAMPS")) return exec_launch_steps(E);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(E->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return exec_launch_steps(E);
+  }
+  if (E->graph_exec && E->graph_aligned != E->outs_aligned16) {   // vector width of the last step changed
+    (void)hipGraphExecDestroy(E->graph_exec);
+    E->graph_exec = nullptr;
+  }
+  if (!E->graph_exec) {
+    if (!E->graph_warm) { E->graph_warm = true; return exec_launch_steps(E); }
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(E->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      E->use_graph = 0;
+      return exec_launch_steps(E);
+    }
+    const int rc = exec_launch_steps(E);
+    const hipError_t ec = hipStreamEndCapture(E->stream, &g);
+    if (rc != CTN_OK || ec != hipSuccess || !g ||
+        hipGraphInstantiate(&E->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (g) (void)hipGraphDestroy(g);
+      E->graph_exec = nullptr;
+      E->use_graph = 0;                      // fall back to eager launches for good
+      return rc != CTN_OK ? rc : exec_launch_steps(E);
+    }
+    (void)hipGraphDestroy(g);
+    E->graph_aligned = E->outs_aligned16;
+  }
+  HIPCHECK(hipGraphLaunch(E->graph_exec, E->stream));
+  return CTN_OK;
+}
+
 static int exec_set_pointers(Exec* E, const void* const* dev_inputs, void* const* dev_outs) {
   const Plan& P = *E->plan;
   const int nt = E->n_tensors;
@@ -599,6 +651,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   const Plan& P = plan->p;
   E.plan = &P; E.device = device; E.R = replicas; E.n_cu = n_cu > 0 ? n_cu : 256;
   if (const char* g = getenv("CTN_MFMA_G")) E.mfma_g = atoi(g);
+  if (const char* g = getenv("CTN_GRAPH")) E.use_graph = atoi(g);
   E.n_tensors = P.n_inputs + P.n_steps + 1;
   auto fail = [&](int code) { delete x; return code; };
 #define HIPCHECK_X(expr)                                                        \

@@ -282,8 +282,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_chain(const ChainStep* __restrict__ steps, int n_steps,
                                                void* const* ptrs, int n_tensors, double* partials,
                                                int R, double min_norm, int stabilize) {
+  constexpr int kStage = 24576 / sizeof(T);   // operand elements staged per step (24 KB; sc[] takes up to 32)
   __shared__ double red[4];
   __shared__ T sc[kChainMaxSteps];
+  __shared__ T stage[kStage];
   const int r = blockIdx.x;
   void* const* tp = ptrs + (size_t)r * n_tensors;
   for (int s = 0; s < n_steps; ++s) {
@@ -294,18 +296,47 @@ __global__ __launch_bounds__(256) void k_chain(const ChainStep* __restrict__ ste
     const T* __restrict__ B = (const T*)tp[d.idB];
     T* __restrict__ C = (T*)tp[d.idC];
     const int total = d.Bt * d.M * d.N;
+    const int na = d.Bt * d.M * d.K, nb = d.Bt * d.N * d.K;
     double absv = 0;
-    for (int o = threadIdx.x; o < total; o += 256) {
-      const int n = o % d.N;
-      const int q = o / d.N;
-      const int m = q % d.M;
-      const int b = q / d.M;
-      const T* pa = A + d.obA[b] + d.omA[m];
-      const T* pb = B + d.obB[b] + d.onB[n];
-      T acc = 0;
-      for (int k = 0; k < d.K; ++k) acc = fma(pa[d.okA[k]] / sA, pb[d.okB[k]] / sB, acc);
-      C[d.obC[b] + d.omC[m] + d.onC[n]] = acc;
-      absv += (double)fabs(acc);
+    if (na + nb <= kStage) {
+      // normalise each operand element ONCE into dense LDS images ([b][m][k] and [b][k][n]); the MAC loop
+      // then has neither divisions nor table look-ups (same operations in the same order as below)
+      T* la = stage;
+      T* lb = stage + na;
+      for (int i = threadIdx.x; i < na; i += 256) {
+        const int k = i % d.K, q = i / d.K;
+        la[i] = A[d.obA[q / d.M] + d.omA[q % d.M] + d.okA[k]] / sA;
+      }
+      for (int i = threadIdx.x; i < nb; i += 256) {
+        const int n = i % d.N, q = i / d.N;
+        lb[i] = B[d.obB[q / d.K] + d.onB[n] + d.okB[q % d.K]] / sB;
+      }
+      __syncthreads();
+      for (int o = threadIdx.x; o < total; o += 256) {
+        const int n = o % d.N;
+        const int q = o / d.N;
+        const int m = q % d.M;
+        const int b = q / d.M;
+        const T* pa = la + (b * d.M + m) * d.K;
+        const T* pb = lb + b * d.K * d.N + n;
+        T acc = 0;
+        for (int k = 0; k < d.K; ++k) acc = fma(pa[k], pb[k * d.N], acc);
+        C[d.obC[b] + d.omC[m] + d.onC[n]] = acc;
+        absv += (double)fabs(acc);
+      }
+    } else {
+      for (int o = threadIdx.x; o < total; o += 256) {
+        const int n = o % d.N;
+        const int q = o / d.N;
+        const int m = q % d.M;
+        const int b = q / d.M;
+        const T* pa = A + d.obA[b] + d.omA[m];
+        const T* pb = B + d.obB[b] + d.onB[n];
+        T acc = 0;
+        for (int k = 0; k < d.K; ++k) acc = fma(pa[d.okA[k]] / sA, pb[d.okB[k]] / sB, acc);
+        C[d.obC[b] + d.omC[m] + d.onC[n]] = acc;
+        absv += (double)fabs(acc);
+      }
     }
     // the barriers inside block_sum also order this step's stores before the next step's loads
     const double tot = block_sum(absv, red);

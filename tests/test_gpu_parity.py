@@ -410,3 +410,35 @@ def test_stabilize_function(shape, dtype):
     got_t, got_c = E.stabilize(tiny, np.asarray(1.25))
     np.testing.assert_array_equal(got_t, tiny)
     assert float(got_c) == 1.25
+
+
+def test_graph_replay_matches_eager_and_follows_new_operands(monkeypatch):
+    """From its third enqueue on an executor replays the launch sequence as one hipGraph: same bits as the
+    eager enqueues, new operand values (same buffers or new ones) are picked up, timing mode stays eager."""
+    from tests import networks as nets
+    from contractn_amd import TN
+
+    tn = nets.peps_closed(TN, 3, 3, 6, dtype=np.float32, seed=4)   # bond 6: too big for the one-launch chain walk
+    ops = [np.asarray(p, dtype=np.float32) for p in tn.params]
+    shapes = [o.shape for o in ops]
+    bc = E.BatchedContraction(tn.einsum_str, shapes, np.float32, replicas=2)
+    assert any(i["kernel"] == 2 for i in bc.plan.step_infos())   # MFMA steps: not a chain-walk plan
+    sets = [ops, [2 * o if i == 0 else o for i, o in enumerate(ops)]]
+    runs = [bc.run_host(sets) for _ in range(5)]           # eager, eager (capture), replay, replay, replay
+    for t, c in runs[1:]:
+        assert np.array_equal(t, runs[0][0]) and np.array_equal(c, runs[0][1])
+    sets2 = [[3 * o if i == 1 else o for i, o in enumerate(ops)], ops]
+    t2, c2 = bc.run_host(sets2)                            # replayed graph, different operand values
+    assert np.array_equal(t2[1], runs[0][0][0]) and float(c2[1]) == float(runs[0][1][0])
+    assert abs(float(c2[0]) - (float(runs[0][1][0]) + np.log(3.0))) < 1e-5
+    bc.executor.set_timing(1)
+    t3, c3 = bc.run_host(sets)                             # event-timed enqueue: eager path, same result
+    assert np.array_equal(t3, runs[0][0]) and np.array_equal(c3, runs[0][1])
+    assert bc.executor.step_ms().shape == (bc.plan.n_steps,)
+    bc.executor.close()
+
+    monkeypatch.setenv("CTN_GRAPH", "0")
+    bc0 = E.BatchedContraction(tn.einsum_str, shapes, np.float32, replicas=2)
+    t0, c0 = bc0.run_host(sets)
+    assert np.array_equal(t0, runs[0][0]) and np.array_equal(c0, runs[0][1])
+    bc0.executor.close()
