@@ -2,10 +2,15 @@
 
 Exercises the label algebra of the planner: batch (kept+shared), free, contracted, summed-out and
 diagonal labels, extent-1 axes, arbitrary output permutations, unary steps, multi-operand paths."""
+import os
+
 import numpy as np
 import pytest
 
 from contractn_amd import contract
+
+# CTN_FUZZ_OFFSET=n shifts every seed: extended runs on a GPU box draw fresh cases without growing the suite
+OFFSET = int(os.environ.get("CTN_FUZZ_OFFSET", "0"))
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +36,7 @@ def random_pair_case(rng):
 
 @pytest.mark.parametrize("seed", range(120))
 def test_random_pairwise_step(seed):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(OFFSET + seed)
     einstr, sizes = random_pair_case(rng)
     lhs = einstr.split("->")[0].split(",")
     ops = [rng.standard_normal([sizes[c] for c in t]) for t in lhs]
@@ -46,7 +51,7 @@ def test_random_pairwise_step(seed):
 @pytest.mark.parametrize("seed", range(40))
 def test_random_network(seed):
     """3-6 operands, random shared labels (hyperedges allowed), auto path."""
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(OFFSET + 1000 + seed)
     n_ops = int(rng.integers(3, 7))
     labels = list(LETTERS[: int(rng.integers(3, 8))])
     sizes = {l: int(rng.choice([2, 3, 4, 6])) for l in labels}
@@ -69,7 +74,7 @@ def test_random_network(seed):
 @pytest.mark.parametrize("seed", range(30))
 def test_random_pairwise_step_f32_larger(seed):
     """fp32 with extents that reach the MFMA / row-dot / vector-stream kernels."""
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(OFFSET + 5000 + seed)
     pool = [1, 2, 4, 8, 12, 32, 40, 64, 100, 128]
     sizes = {l: int(rng.choice(pool)) for l in "abcde"}
     ta = "".join(rng.choice(list("abcde"), size=int(rng.integers(1, 4)), replace=False))
@@ -83,7 +88,9 @@ def test_random_pairwise_step_f32_larger(seed):
     t_hat, c = contract(einstr, *ops, split_format=True)
     got = np.asarray(t_hat, dtype=np.float64) * np.exp(float(c))
     scale = max(np.max(np.abs(ref)), 1e-300)
-    assert np.max(np.abs(got - ref)) <= 2e-4 * scale, (einstr, sizes)
+    # a sum that cancels (e.g. 'ec,a->' over zero-mean data) is only accurate relative to its TERMS in fp32
+    terms = np.max(np.einsum(einstr, *[np.abs(o).astype(np.float64) for o in ops]))
+    assert np.max(np.abs(got - ref)) <= 2e-4 * scale + 2e-6 * terms, (einstr, sizes)
 
 
 def _large_tile_case(rng, dtype="float32"):
@@ -117,7 +124,7 @@ def test_random_large_tile_steps_f32(seed, monkeypatch):
     from contractn_amd import einsum as E
     monkeypatch.setenv("CTN_MFMA_G", "2")       # take the large-tile kernel whenever the planner allows it
     E.clear_caches()
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(OFFSET + 9000 + seed)
     einstr, sizes = _large_tile_case(rng)
     lhs = einstr.split("->")[0].split(",")
     ops = [rng.standard_normal([sizes[c] for c in t]).astype(np.float32) for t in lhs]
@@ -134,7 +141,7 @@ def test_random_large_tile_steps_f64(seed, monkeypatch):
     from contractn_amd import einsum as E
     monkeypatch.setenv("CTN_MFMA_G", "2")
     E.clear_caches()
-    rng = np.random.default_rng(9500 + seed)
+    rng = np.random.default_rng(OFFSET + 9500 + seed)
     einstr, sizes = _large_tile_case(rng, "float64")
     lhs = einstr.split("->")[0].split(",")
     ops = [rng.standard_normal([sizes[c] for c in t]) for t in lhs]
