@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_chain(const ChainStep* __restrict__ ste
     const int total = d.Bt * d.M * d.N;
     const int na = d.Bt * d.M * d.K, nb = d.Bt * d.N * d.K;
     double absv = 0;
-    if (na + nb <= kStage) {
+    if (d.K >= 4 && na + nb <= kStage) {   // a real K loop to amortise the staging pass
       // normalise each operand element ONCE into dense LDS images ([b][m][k] and [b][k][n]); the MAC loop
       // then has neither divisions nor table look-ups (same operations in the same order as below)
       T* la = stage;

@@ -39,13 +39,17 @@ def run_device(einstr, shapes, path, replicas=1, iters=5, seed=0, scale=1.0, dty
     out = torch.zeros((replicas,) + tuple(bc.plan.out_shape), device="cuda", dtype=tdt)
     launch = bc.executor.make_enqueue([t.data_ptr() for r in ops for t in r], [out[r].data_ptr() for r in range(replicas)])
     launch()
+    launch()
     bc.executor.synchronize()
-    bc.executor.set_timing(iters)
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()           # wall time of plain enqueues (hipGraph replay, no per-step events)
     for _ in range(iters):
         launch()
     bc.executor.synchronize()
     wall = (time.perf_counter() - t0) / iters
+    bc.executor.set_timing(iters)      # then the per-kernel breakdown from event-bracketed enqueues
+    for _ in range(iters):
+        launch()
+    bc.executor.synchronize()
     ms = bc.executor.step_ms()
     infos = bc.plan.step_infos()
     by = {}
@@ -84,6 +88,19 @@ def cfg3b(batch=4096, n_sites=100, bond=256, phys=4):
     path = ssa_to_linear(nets.batched_mps_path(n_sites), 2 * n_sites)
     bc, ops, out, wall, ms, by = run_device(tn.einsum_str, shapes, path, replicas=1, scale=16.0 ** 0.5)
     summarize(f"3b batched MPS B={batch} sites={n_sites} D={bond}", bc, wall, by, 1)
+
+
+def cfg3a(sites=100, bond=256, phys=4):
+    """The metric's network at the replica counts SURVEY.md 8(d) names (bench.py runs it at R = 512)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    tn, einstr, shapes, path = bench.build_network(sites, bond, phys)
+    for R in (1, 8, 64):
+        bc, ops, out, wall, ms, by = run_device(einstr, shapes, path, replicas=R, iters=10, scale=16.0)
+        summarize(f"3a MPS-{sites} overlap D={bond} d={phys} zipper", bc, wall, by, R)
+        del ops, out, bc
+        torch.cuda.empty_cache()
 
 
 def cfg4():
@@ -198,9 +215,11 @@ def cfg12():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg3b", "cfg4", "cfg5"]
+    which = sys.argv[1:] or ["cfg1", "cfg3a", "cfg3b", "cfg4", "cfg5"]
     if "cfg1" in which or "cfg2" in which:
         cfg12()
+    if "cfg3a" in which:
+        cfg3a()
     if "cfg3b" in which:
         cfg3b(batch=4096)
         cfg3b(batch=1024)
