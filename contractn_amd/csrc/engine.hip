@@ -304,7 +304,10 @@ static int exec_launch_steps(Exec* E) {
         const bool kcontig = st.modeA == 2 || st.modeB == 2;
         // ... and K >= 192: below that the 128-tile kernel's 3-4 workgroups per CU hide the per-tile cost
         // better (8192 x 8192 x K: K = 64 old +7 %, 128 +2 %, 192 equal, 256 large tiles +5 %)
-        if (use_g && st.tileM == GM && a.c_vec && (use_g >= 2 || (gtiles >= 2LL * E->n_cu && st.K >= 192))) {
+        // ... and long K (>= 1024) already from 3/4 of a tile per CU: the per-tile cost amortises over the k loop
+        // (256 x 256 x 1024 per replica, R = 96 / 128: 86.9 / 106.2 vs 80.3 / 95.8 TFLOP/s; R = 48 / 64 lose)
+        if (use_g && st.tileM == GM && a.c_vec &&
+            (use_g >= 2 || (gtiles >= 2LL * E->n_cu && st.K >= 192) || (st.K >= 1024 && 4 * gtiles >= 3LL * E->n_cu))) {
           a.tiles_m = (int32_t)((st.M + GM - 1) / GM);
           // long-K steps on narrow outputs whose tiles are all full also exist as 256 x 256 tiles (8 waves, one
           // workgroup per CU): with N <= 512 each A tile is fetched half as often (256 x 256 x 1024 per replica:
