@@ -29,6 +29,7 @@
 #include "kernel_args.h"
 #include "kernels_mfma.h"
 #include "kernels_mfma_g.h"
+#include "kernels_mfma_g2.h"
 #include "kernels_mfma_g64.h"
 #include "kernels_stream.h"
 
@@ -338,6 +339,12 @@ static int exec_launch_steps(Exec* E) {
             const dim3 gg((unsigned)((int64_t)a.blocks_per_replica * R));
             // hand-scheduled blocks for whole k-tiles, the C++ loop (which masks a ragged last k-tile) otherwise
             const bool use_asm = st.K % GK == 0 && !no_asm;
+            // CTN_MFMA_G2=1 (experiment): two-stage ring, three workgroups per CU (kernels_mfma_g2.h)
+            static const bool g2 = [] { const char* e = getenv("CTN_MFMA_G2"); return e && atoi(e) == 1; }();
+            if (g2 && use_asm && !kcontig) {
+              hipLaunchKernelGGL(k_mfma_f32_g2, gg, dim3(256), 0, E->stream, a);
+              break;
+            }
 #define CTN_G_LAUNCH(AA, BB)                                                                             \
             do {                                                                                         \
               if (use_asm) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, AA, BB>), gg, dim3(256), 0, E->stream, a); \
