@@ -58,6 +58,7 @@ struct Exec {
   int n_tensors = 0;
   int n_cu = 256;
   int mfma_g = 1;        // CTN_MFMA_G at creation time (see exec_launch_steps)
+  int mfma_g2 = 0;       // CTN_MFMA_G2 at creation time
   // the launch sequence as a hipGraph (CTN_GRAPH, see exec_launch_all): captured on the second enqueue,
   // replayed afterwards; tensors are reached through the device pointer table, so new operands need no update
   int use_graph = 1;
@@ -340,8 +341,7 @@ static int exec_launch_steps(Exec* E) {
             // hand-scheduled blocks for whole k-tiles, the C++ loop (which masks a ragged last k-tile) otherwise
             const bool use_asm = st.K % GK == 0 && !no_asm;
             // CTN_MFMA_G2=1 (experiment): two-stage ring, three workgroups per CU (kernels_mfma_g2.h)
-            static const bool g2 = [] { const char* e = getenv("CTN_MFMA_G2"); return e && atoi(e) == 1; }();
-            if (g2 && use_asm && !kcontig) {
+            if (E->mfma_g2 && use_asm && !kcontig) {
               hipLaunchKernelGGL(k_mfma_f32_g2, gg, dim3(256), 0, E->stream, a);
               break;
             }
@@ -662,6 +662,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   E.plan = &P; E.device = device; E.R = replicas; E.n_cu = n_cu > 0 ? n_cu : 256;
   if (const char* g = getenv("CTN_MFMA_G")) E.mfma_g = atoi(g);
   if (const char* g = getenv("CTN_GRAPH")) E.use_graph = atoi(g);
+  if (const char* g = getenv("CTN_MFMA_G2")) E.mfma_g2 = atoi(g) == 1;
   E.n_tensors = P.n_inputs + P.n_steps + 1;
   auto fail = [&](int code) { delete x; return code; };
 #define HIPCHECK_X(expr)                                                        \

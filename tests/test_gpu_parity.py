@@ -442,3 +442,25 @@ def test_graph_replay_matches_eager_and_follows_new_operands(monkeypatch):
     t0, c0 = bc0.run_host(sets)
     assert np.array_equal(t0, runs[0][0]) and np.array_equal(c0, runs[0][1])
     bc0.executor.close()
+
+
+@pytest.mark.parametrize("einstr,shapes", [
+    ("km,kn->mn", [(32, 256), (32, 128)]),              # one tile, two k-tiles (the ring's minimum)
+    ("km,kn->mn", [(256, 512), (256, 384)]),            # 2 x 3 tiles, 16 k-tiles: both stages reused 8 times
+    ("xkm,xkn->xmn", [(2, 48, 400), (2, 48, 200)]),     # batch label, ragged M and N
+])
+def test_two_stage_ring_variant(einstr, shapes, force_large_tiles, monkeypatch):
+    """CTN_MFMA_G2=1: the 256 x 128 kernel with a two-stage ring and three workgroups per CU (k_mfma_f32_g2)."""
+    monkeypatch.setenv("CTN_MFMA_G2", "1")
+    E.clear_caches()
+    rng = np.random.default_rng(41)
+    ops = [(rng.standard_normal(s) * rng.uniform(0.5, 3.0)).astype(np.float32) for s in shapes]
+    t_hat, c = contract(einstr, *ops, split_format=True)
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    got = t_hat.astype(np.float64) * np.exp(float(c))
+    assert np.max(np.abs(got - ref)) <= 2e-4 * np.max(np.abs(ref))
+    assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-5
+    monkeypatch.setenv("CTN_MFMA_G2", "0")
+    E.clear_caches()
+    t_ref, c_ref = contract(einstr, *ops, split_format=True)     # same k order per element: same bits as the 3-stage kernel
+    assert np.array_equal(t_hat, t_ref) and float(c) == float(c_ref)
