@@ -90,9 +90,52 @@ void run(int ncu, int wps) {
   hipFree(out); hipFree(st);
 }
 
-int main() {
+// `mfma_shape_probe power`: each shape for ~4 s back to back, so that the power controller settles; prints the
+// rate and in-kernel clock of the last second (is one shape cheaper in energy per flop = faster at the cap?)
+template <int SHAPE, bool LDS>
+void run_settled(int ncu, int wps, double seconds) {
+  const int iters = 12000, blocks = ncu * wps, threads = 256;
+  float* out; unsigned long long* st;
+  hipMalloc(&out, (size_t)blocks * threads * 4);
+  hipMalloc(&st, (size_t)blocks * 16);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k_probe<SHAPE, LDS, 0>), dim3(blocks), dim3(threads), 0, 0, out, st, iters);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k_probe<SHAPE, LDS, 0>), dim3(blocks), dim3(threads), 0, 0, out, st, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms1; hipEventElapsedTime(&ms1, e0, e1);
+  const int n = (int)(seconds * 1e3 / ms1) + 1, tail = n / 4 + 1;
+  for (int w = 0; w < n - tail; ++w) hipLaunchKernelGGL((k_probe<SHAPE, LDS, 0>), dim3(blocks), dim3(threads), 0, 0, out, st, iters);
+  hipEventRecord(e0);
+  for (int w = 0; w < tail; ++w) hipLaunchKernelGGL((k_probe<SHAPE, LDS, 0>), dim3(blocks), dim3(threads), 0, 0, out, st, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= tail;
+  std::vector<unsigned long long> h(blocks * 2);
+  hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> clk;
+  for (int b = 0; b < blocks; ++b) clk.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 100.0);
+  std::sort(clk.begin(), clk.end());
+  const double flops = (double)blocks * 4 * iters * 8.0 * 4 * 4096.0;
+  printf("settled %.0f s: shape %dx%d %s waves/SIMD %d: first launch %6.1f TFLOP/s, last quarter %6.1f TFLOP/s, clock median %.0f MHz\n",
+         seconds, SHAPE, SHAPE, LDS ? "LDS-fed" : "reg-fed", wps, flops / (ms1 * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12,
+         clk[clk.size() / 2]);
+  fflush(stdout);
+  hipFree(out); hipFree(st);
+}
+
+int main(int argc, char** argv) {
   int ncu = 256;
   hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
+  if (argc > 1) {
+    for (int rep = 0; rep < 2; ++rep) {
+      run_settled<32, true>(ncu, 2, 4.0);
+      run_settled<16, true>(ncu, 2, 4.0);
+    }
+    run_settled<32, false>(ncu, 2, 4.0);
+    run_settled<16, false>(ncu, 2, 4.0);
+    return 0;
+  }
   for (int rep = 0; rep < 1; ++rep)
     for (int wps = 1; wps <= 2; ++wps) {
       run<32, false>(ncu, wps); run<16, false>(ncu, wps);
