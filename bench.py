@@ -135,6 +135,10 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # an executor captures its launch sequence as a hipGraph on its second enqueue: with fewer than two warm-up
+    # steps that one-off (a few ms) would land in the timed region, so the missing enqueues are issued here
+    for _ in range(max(0, 2 - args.warmup)):
+        launch()
     for _ in range(args.warmup):
         launch()
     sync_all()
