@@ -16,6 +16,11 @@ namespace ctn {
 // instruction, and one instruction is one k-row), which spreads the four k-rows that a fragment read
 // touches over different banks.
 //
+// Residency: the 51.7 KB of LDS admit three workgroups per CU; the mode-1 instance is bounded to 168 registers
+// for that (15 spilled, all outside the k-loop): MPS shapes at 256 replicas 55.3 / 57.9 -> 56.8 / 58.9 TFLOP/s, 8192^3
+// 69.4 -> 71.4, the fp64 headline 2362 -> 2401 /s.  The k-contiguous instances spill into the loop at that bound
+// (row-major 4096^3: 64.7 -> 55.4) and stay at two.
+//
 // Eligibility (planner): both operands unit-stride along their free index ("mode 1", pairs of
 // doubles), K >= 16, C pair-storable; ragged M / N / K handled as in the fp32 kernel.
 // ---------------------------------------------------------------------------
@@ -34,7 +39,7 @@ __device__ __forceinline__ void glds16d(const double* g, double* lds) {
 // consecutive k), LDS image [k / 2][rows][2] with the four chunks 260 doubles apart, and BOTH operands read in
 // the permuted k order k(ks, q) = 2 q + ks (q = lane / 16), which puts a lane's two k-steps into one chunk.
 template <int MA = 1, int MB = 1>
-__global__ __launch_bounds__(256, 2) void k_mfma_f64_g(StepArgs a) {
+__global__ __launch_bounds__(256, (MA == 1 && MB == 1) ? 3 : 2) void k_mfma_f64_g(StepArgs a) {
   constexpr bool PERM = MA == 2 || MB == 2;
   constexpr int DCH = 260;   // doubles between the k-chunks of a k-contiguous operand's image (256 + 4 pad)
   // ONE LDS object: [stage 0 A|B][stage 1 A|B][stage 2 A|B][red 4 doubles]
