@@ -1,0 +1,38 @@
+"""bench.py end to end on a small instance of the metric's network: the JSON contract of the driver
+(one line; metric / value / unit / n_gpus / steps / warmup / ms_per_step / scaling / dtype / config.workload)
+plus the `roofline` and `cpu_baseline` objects, and the oracle check that the N = 1 run carries."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_bench_line_contract(dtype):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--sites", "12", "--bond", "64", "--replicas", "8", "--cpu-seconds", "0.5", "--dtype", dtype]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["unit"] == "contractions/s" and r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["dtype"] == dtype and r["value"] > 0 and "workload" in r["config"] and "model" not in r["config"]
+    roof = r["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert roof["peak"] == (157.3 if dtype == "f32" else 78.6)
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    cpu = r["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert cpu["parity_vs_gpu"]["ok"] is True          # replica 0 of this very run against the oracle
+    assert r["device"]["compute_units"] > 0
