@@ -132,3 +132,29 @@ def test_memory_limit_steers_the_search():
     assert tight[1] <= max(free[1], 200) or tight[1] <= free[1]
     cl = paths.contraction_list(einstr, shapes, optimize="dp", memory_limit="max_input")
     assert len(cl) == 3
+
+
+def test_auto_restarts_only_where_greedy_is_not_flat():
+    """'auto' beyond 12 operands: a greedy path whose intermediates never outgrow the largest operand is taken as
+    is (hub / chain: milliseconds), a lattice gets noisy restarts (8 x 8 PEPS: several times cheaper than greedy)."""
+    import time
+
+    from contractn_amd import TN
+    from tests import networks as nets
+
+    tn = TN()
+    hub = tn.add_copy_node(101)
+    for i in range(100):
+        tn.connect_nodes(hub, tn.add_dense_node(np.array([1, 0.99])), i, 0)
+    terms, out, sizes = paths.parse_einsum_input(tn.einsum_str, [p.shape for p in tn.params])
+    t0 = time.perf_counter()
+    auto = paths.find_path(terms, out, sizes, "auto")
+    assert time.perf_counter() - t0 < 0.2
+    assert paths.path_cost(terms, out, sizes, auto) == paths.path_cost(terms, out, sizes, paths.find_path(terms, out, sizes, "greedy"))
+
+    tn = nets.peps_closed(TN, 6, 6, 2, dtype=np.float32, seed=6)
+    shapes = [tuple(6 if (d == 2 and p.ndim > 1 and ax > 0) else d for ax, d in enumerate(p.shape)) for p in tn.params]
+    terms, out, sizes = paths.parse_einsum_input(tn.einsum_str, shapes)
+    c_auto = paths.path_cost(terms, out, sizes, paths.find_path(terms, out, sizes, "auto"))
+    c_greedy = paths.path_cost(terms, out, sizes, paths.find_path(terms, out, sizes, "greedy"))
+    assert c_auto <= c_greedy
