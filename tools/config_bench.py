@@ -140,6 +140,16 @@ def cfg5(rows=8, cols=8, bond=8):
     bc, ops, out, wall, ms, by = run_device(tn.einsum_str, shapes, path, replicas=1, iters=3, scale=bond ** 0.5)
     summarize(f"5 PEPS {rows}x{cols} D={bond} row sweep (unsliced)", bc, wall, by, 1,
               {"largest_intermediate": max(i["out_numel"] for i in bc.plan.step_infos())})
+    del ops, out, bc
+    torch.cuda.empty_cache()
+    # the same network on the path the library finds by itself (optimize="auto": noisy greedy + subtree reconfiguration)
+    t0 = time.perf_counter()
+    terms, out_l, sizes = E.paths.parse_einsum_input(tn.einsum_str, shapes)
+    auto = tuple(E.paths.find_path(terms, out_l, sizes, "auto"))
+    search_s = time.perf_counter() - t0
+    bc, ops, out, wall, ms, by = run_device(tn.einsum_str, shapes, auto, replicas=1, iters=3, scale=bond ** 0.5)
+    summarize(f"5 PEPS {rows}x{cols} D={bond} optimize='auto' path", bc, wall, by, 1,
+              {"largest_intermediate": max(i["out_numel"] for i in bc.plan.step_infos()), "path_search_s": round(search_s, 2)})
 
 
 def cfg5_sliced(rows=8, cols=8, bond=8, n_bonds=3):
