@@ -111,3 +111,25 @@ def test_choose_slices_bounds_memory_and_feeds_the_sliced_contraction():
     t_s, c_s = dist.contract_sliced(tn.einsum_str, ops, labels, contract_fn=oracle_contract)
     t_u, c_u = oracle_contract(tn.einsum_str, *ops)
     np.testing.assert_allclose(np.asarray(t_s) * np.exp(float(c_s)), np.asarray(t_u) * np.exp(float(c_u)), rtol=1e-10)
+
+
+def test_choose_slices_with_path_co_optimises_and_reproduces_the_value():
+    """Slice labels chosen together with the path: enough slices, bounded overhead, a smaller peak than a fixed
+    path gives, and the sliced contraction on the returned path equals the unsliced one."""
+    from contractn_amd import TN, dist
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+
+    tn = nets.peps_closed(TN, 4, 4, 3, dtype=np.float64, seed=9)
+    ops = list(tn.params)
+    shapes = [o.shape for o in ops]
+    labels, path, rep = dist.choose_slices_with_path(tn.einsum_str, shapes, min_slices=8, trials=2)
+    assert rep["slices"] >= 8 and len(labels) >= 2
+    assert rep["largest_intermediate"] <= rep["unsliced_largest_intermediate"]
+    fixed_labels, fixed = dist.choose_slices(tn.einsum_str, shapes, optimize=ssa_to_linear(nets.peps_row_path(4, 4), 32),
+                                             min_slices=8)
+    assert rep["work_overhead"] <= fixed["work_overhead"] * 1.5 + 1.0     # never far above the fixed-path choice
+    t_s, c_s = dist.contract_sliced(tn.einsum_str, ops, labels, contract_fn=lambda e, *o, **kw: cpu_ref.contract(
+        e, *o, path=list(path), split_format=kw.get("split_format", True)))
+    t_u, c_u = oracle_contract(tn.einsum_str, *ops)
+    np.testing.assert_allclose(np.asarray(t_s) * np.exp(float(c_s)), np.asarray(t_u) * np.exp(float(c_u)), rtol=1e-9)
