@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--event-passes", type=int, default=3, help="timed passes bracketed by HIP events")
     ap.add_argument("--dump-steps", default=None, help="write per-step kernel info + mean ms to this JSON file")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline time budget")
+    ap.add_argument("--path", choices=["zipper", "auto"], default="zipper",
+                    help="zipper = the explicit path of the metric's config (SURVEY.md 8d); auto = what the library's "
+                         "own path search returns for this network (exploration; the workload label says so)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32",
                     help="f32 = the BASELINE metric; f64 = the same workload in double precision (secondary)")
     return ap.parse_args()
@@ -94,6 +97,11 @@ def main():
 
     R = args.replicas
     tn, einstr, shapes, path = build_network(args.sites, args.bond, args.phys)
+    if args.path == "auto":
+        from contractn_amd import paths as _paths
+
+        _terms, _out, _sizes = _paths.parse_einsum_input(einstr, shapes)
+        path = tuple(tuple(p) for p in _paths.find_path(_terms, _out, _sizes, "auto"))
     S = max(1, args.streams)
     assert R % S == 0, "--replicas must be a multiple of --streams"
     Rg = R // S
@@ -233,7 +241,7 @@ def main():
         "dtype": args.dtype,
         "data": "synthetic (standard normal / 16, on-device generator, seeds 3+replica)",
         "config": {
-            "workload": f"mps_overlap_{args.sites}sites_D{args.bond}_d{args.phys}_zipper_R{R}",
+            "workload": f"mps_overlap_{args.sites}sites_D{args.bond}_d{args.phys}_{args.path}_R{R}",
             "replicas_per_gpu": R,
             "steps_per_contraction": plan.n_steps,
             "flop_per_contraction": flops_per,
