@@ -160,3 +160,20 @@ def test_cfg5_device_resident_slicing_zero_copy():
     assert small.R == 1 and len(small._chunks) == 64
     tk, ck = small.run()
     assert abs(full(tk, ck) - full(t, c)) <= 2e-3 * abs(full(t, c))
+
+
+def test_cfg5_peps_on_the_librarys_own_path_and_co_optimised_slices():
+    """6 x 6 PEPS, bond 4: `optimize="auto"` (noisy greedy + subtree reconfiguration) and slices chosen together
+    with their path (`dist.choose_slices_with_path`, run device-resident as replicas) give the row sweep's value."""
+    rows = cols = 6
+    tn = nets.peps_closed(TN, rows, cols, 4, dtype=np.float32, seed=6)
+    ops = list(tn.params)
+    row = ssa_to_linear(nets.peps_row_path(rows, cols), 2 * rows * cols)
+    t, c = tn.contract(optimize=row, split_format=True)
+    ta, ca = tn.contract(optimize="auto", split_format=True)
+    assert float(ta) == float(t) and abs(float(ca) - float(c)) <= 2e-5 * abs(float(c))
+    labels, path, rep = dist.choose_slices_with_path(tn.einsum_str, [o.shape for o in ops], min_slices=16, trials=2)
+    assert rep["slices"] >= 16
+    sc = dist.SlicedContraction(tn.einsum_str, ops, labels, optimize=path, rank=0, world=1)
+    ts, cs = sc.run()
+    assert abs(full(ts, cs) - full(t, c)) <= 2e-3 * abs(full(t, c))
