@@ -490,8 +490,12 @@ def find_path(terms, out, sizes, optimize, memory_limit=None):
             biggest_in = max((_size(t, sizes) for t in sets), default=1)
             if not hq and path_cost(sets, out, sizes, path)[1] <= biggest_in:
                 return path
-            return _reconfigure(sets, out, sizes, path, max_leaves=10 if hq else (8 if n <= 256 else 6),
-                                rounds=12 if hq else 8, memory_limit=memory_limit)
+            better = _reconfigure(sets, out, sizes, path, max_leaves=10 if hq else (8 if n <= 256 else 6),
+                                  rounds=12 if hq else 8, memory_limit=memory_limit)
+            # fewer flops must not buy an intermediate the engine cannot hold (2^31 elements) when the start fits
+            if path_cost(sets, out, sizes, better)[1] >= (1 << 31) > path_cost(sets, out, sizes, path)[1]:
+                return path
+            return better
     if name == "optimal" and n <= 8 and memory_limit is None:
         return _optimal(sets, out, sizes)
     if name in ("optimal", "dp", "branch-all", "branch-2", "branch-1"):
