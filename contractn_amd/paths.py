@@ -279,10 +279,11 @@ def _dp(term_sets, out, sizes, memory_limit=None):
     return _ssa_pairs_to_linear(pairs, n)
 
 
-def _random_greedy(term_sets, out, sizes, repeats=32, seed=0, memory_limit=None, accept_flat=False):
+def _random_greedy(term_sets, out, sizes, repeats=32, seed=0, memory_limit=None, accept_flat=False, keep=1):
     """Greedy restarts with Boltzmann noise on the pair score (the idea of opt_einsum's
     ``'random-greedy'``): the first trial is the plain greedy path, the best path by flop count
-    (then by largest intermediate) wins.  Deterministic for a given seed."""
+    (then by largest intermediate) wins.  Deterministic for a given seed.  ``keep`` > 1 returns the
+    ``keep`` best distinct trials, best first (starting points for `_reconfigure`)."""
     import math
     import random
 
@@ -294,7 +295,8 @@ def _random_greedy(term_sets, out, sizes, repeats=32, seed=0, memory_limit=None,
     # accept_flat ("auto"): a greedy path none of whose intermediates outgrows the largest operand (chains,
     # hubs, MPS overlaps) leaves the restarts nothing to find - skip them (a 101-leg hub: 1 ms instead of 0.8 s)
     if accept_flat and best_key[1] <= max((_size(t, sizes) for t in term_sets), default=1) and best_key[0] < (1 << 200):
-        return best_path
+        return best_path if keep == 1 else [best_path]
+    trials = [(best_key, best_path)]
     out_set = set(out)
     for trial in range(1, repeats):
         temperature = 0.3 * (1 + trial % 4)
@@ -327,9 +329,17 @@ def _random_greedy(term_sets, out, sizes, repeats=32, seed=0, memory_limit=None,
         key = path_cost(term_sets, out, sizes, path)
         if memory_limit is not None and key[1] > memory_limit:
             key = (key[0] + (1 << 200), key[1])
+        trials.append((key, path))
         if key < best_key:
             best_key, best_path = key, path
-    return best_path
+    if keep == 1:
+        return best_path
+    ranked, seen = [], set()
+    for key, path in sorted(trials, key=lambda kp: kp[0]):
+        if key not in seen:
+            seen.add(key)
+            ranked.append(path)
+    return ranked[:keep]
 
 
 def _reconfigure(term_sets, out, sizes, path, max_leaves=8, rounds=8, memory_limit=None):
@@ -486,12 +496,17 @@ def find_path(terms, out, sizes, optimize, memory_limit=None):
             # overlaps), which is taken as it is.  All of it is cached per network by the caller.
             hq = name == "auto-hq"
             repeats = 128 if hq else (8 if n <= 64 else (4 if n <= 256 else 1))
-            path = _random_greedy(sets, out, sizes, repeats=repeats, memory_limit=memory_limit, accept_flat=not hq)
+            starts = _random_greedy(sets, out, sizes, repeats=repeats, memory_limit=memory_limit, accept_flat=not hq,
+                                    keep=4 if hq else 2)[:4 if hq else 1]
+            path = starts[0]
             biggest_in = max((_size(t, sizes) for t in sets), default=1)
             if not hq and path_cost(sets, out, sizes, path)[1] <= biggest_in:
                 return path
-            better = _reconfigure(sets, out, sizes, path, max_leaves=10 if hq else (8 if n <= 256 else 6),
-                                  rounds=12 if hq else 8, memory_limit=memory_limit)
+            # the refinement is a local search on a rugged landscape: the best start is not always the best finish,
+            # so auto-hq refines its four best trials and keeps the cheapest result (auto: the best trial only)
+            better = min((_reconfigure(sets, out, sizes, st, max_leaves=10 if hq else (8 if n <= 256 else 6),
+                                       rounds=12 if hq else 8, memory_limit=memory_limit) for st in starts),
+                         key=lambda q: path_cost(sets, out, sizes, q))
             # fewer flops must not buy an intermediate the engine cannot hold (2^31 elements) when the start fits
             if path_cost(sets, out, sizes, better)[1] >= (1 << 31) > path_cost(sets, out, sizes, path)[1]:
                 return path
