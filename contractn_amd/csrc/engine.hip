@@ -74,6 +74,7 @@ struct Exec {
   double* d_partials = nullptr;
   double* d_scratch = nullptr;
   void* d_slab = nullptr;           // split-K partial tiles (latency mode), sized at creation
+  void* d_slab2 = nullptr;          // 1/16 of it: where more than 16 slabs are folded 16 to 1 (k_splitk_fold)
   std::vector<int> step_partials;   // abs-sum partials per replica of every step (plan value unless split-K)
   double* d_log = nullptr;
   double* d_resc = nullptr;
@@ -95,7 +96,7 @@ struct Exec {
 
   ~Exec() {
     (void)hipSetDevice(device);
-    for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch, (void*)d_slab,
+    for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch, (void*)d_slab, (void*)d_slab2,
                     (void*)d_log, (void*)d_resc, (void*)d_logs, (void*)d_chain, d_ones, (void*)d_stepP, (void*)d_stepNumel,
                     (void*)d_stage_in, (void*)d_stage_out})
       if (p) (void)hipFree(p);
@@ -165,6 +166,11 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype) {
   return (int)S;
 }
 
+// the reduce pass of a split-K step: fold 16 to 1 while more than 16 slabs are left (ping-pong between the two
+// slab buffers), then the final pass (rescale, C, abs-sum partials)
+template <typename T>
+static void launch_splitk_reduce(Exec* E, int partials, int R, const StepArgs& a, SplitKArgs sk);
+
 template <int MA>
 static void launch_sk_b(int mb, dim3 grid, hipStream_t st, const StepArgs& a, const SplitKArgs& sk) {
   switch (mb) {
@@ -197,6 +203,23 @@ static void launch_sk64(int ma, int mb, dim3 grid, hipStream_t st, const StepArg
     case 2: launch_sk64_b<2>(mb, grid, st, a, sk); break;
     default: launch_sk64_b<0>(mb, grid, st, a, sk); break;
   }
+}
+
+template <typename T>
+static void launch_splitk_reduce(Exec* E, int partials, int R, const StepArgs& a, SplitKArgs sk) {
+  T* bufs[2] = {(T*)E->d_slab, (T*)E->d_slab2};
+  int cur = 0;
+  while (sk.S > 16 && E->d_slab2) {
+    const int S_out = (sk.S + 15) / 16;
+    constexpr int V = 16 / sizeof(T);
+    const dim3 grid((unsigned)((sk.numelC + 256 * V - 1) / (256 * V)), (unsigned)S_out, (unsigned)R);
+    hipLaunchKernelGGL(k_splitk_fold<T>, grid, dim3(256), 0, E->stream, (const T*)bufs[cur], bufs[cur ^ 1],
+                       sk.numelC, sk.S, S_out);
+    cur ^= 1;
+    sk.S = S_out;
+  }
+  sk.slab = bufs[cur];
+  hipLaunchKernelGGL(k_splitk_reduce<T>, dim3(partials, R), dim3(256), 0, E->stream, a, sk);
 }
 
 static int exec_launch_steps(Exec* E) {
@@ -280,7 +303,7 @@ static int exec_launch_steps(Exec* E) {
           sk.tiles_per_replica = (int32_t)(st.Bt * sk.tiles_m * sk.tiles_n);
           used_tile(64, 64);
           launch_sk(st.modeA, st.modeB, dim3((unsigned)((int64_t)sk.tiles_per_replica * sk.S * R)), E->stream, a, sk);
-          hipLaunchKernelGGL(k_splitk_reduce<float>, dim3(E->step_partials[s], R), dim3(256), 0, E->stream, a, sk);
+          launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
           break;
         }
         a.tiles_n = (int32_t)((st.N + st.tileN - 1) / st.tileN);
@@ -388,7 +411,7 @@ static int exec_launch_steps(Exec* E) {
           sk.tiles_per_replica = (int32_t)(st.Bt * sk.tiles_m * sk.tiles_n);
           used_tile(64, 64);
           launch_sk64(st.modeA, st.modeB, dim3((unsigned)((int64_t)sk.tiles_per_replica * sk.S * R)), E->stream, a, sk);
-          hipLaunchKernelGGL(k_splitk_reduce<double>, dim3(E->step_partials[s], R), dim3(256), 0, E->stream, a, sk);
+          launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
           break;
         }
         a.tiles_m = (int32_t)((st.M + kTile64M - 1) / kTile64M);
@@ -689,6 +712,12 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
       if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype))
         slab_elems = std::max(slab_elems, (size_t)S * (size_t)P.tensors[st.out].numel * (size_t)replicas);
     if (slab_elems) HIPCHECK_X(hipMalloc((void**)&E.d_slab, slab_elems * (P.dtype == CTN_F64 ? 8 : 4)));
+    size_t fold_elems = 0;   // a step with more than 16 slabs folds them 16 to 1 into this buffer and back
+    for (const Step& st : P.steps)
+      if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype))
+        if (S > 16)
+          fold_elems = std::max(fold_elems, (size_t)((S + 15) / 16) * (size_t)P.tensors[st.out].numel * (size_t)replicas);
+    if (fold_elems) HIPCHECK_X(hipMalloc((void**)&E.d_slab2, fold_elems * (P.dtype == CTN_F64 ? 8 : 4)));
   }
   // partial counts: the split-K reduce pass spreads over up to 64 workgroups per replica
   E.step_partials.resize(P.n_steps);

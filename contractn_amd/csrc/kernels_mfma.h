@@ -514,6 +514,43 @@ __device__ __forceinline__ T splitk_reduce_span(const T* __restrict__ slab, T* _
   return asum;
 }
 
+// More than 16 slabs (a huge K against a small output, e.g. 64 x 64 x 2,097,152 = 512 slabs): fold them
+// 16 to 1 first - slab g of dst = slabs 16 g .. 16 g + 15 of src, summed in order, every (vector, group) its
+// own thread with all 16 loads in flight - until at most 16 are left for k_splitk_reduce.  (One thread
+// walking 512 slabs took 469 us of a 670 us step.)  grid (element spans, groups, R); any numelC.
+template <typename T>
+__global__ __launch_bounds__(256) void k_splitk_fold(const T* __restrict__ src, T* __restrict__ dst, int64_t numelC,
+                                                     int S_in, int S_out) {
+  constexpr int V = 16 / sizeof(T);
+  struct alignas(16) Vec { T x[V]; };
+  const int r = blockIdx.z, g = blockIdx.y;
+  const int s0 = 16 * g, ns = min(16, S_in - s0);
+  const T* __restrict__ in = src + ((size_t)r * S_in + s0) * numelC;
+  T* __restrict__ out = dst + ((size_t)r * S_out + g) * numelC;
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+  if (i >= numelC) return;
+  if ((numelC & (V - 1)) == 0) {
+    Vec x[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      if (s < ns) x[s] = *reinterpret_cast<const Vec*>(in + (size_t)s * numelC + i);
+    Vec v = x[0];
+#pragma unroll
+    for (int s = 1; s < 16; ++s)
+      if (s < ns) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) v.x[e] += x[s].x[e];
+      }
+    *reinterpret_cast<Vec*>(out + i) = v;
+  } else {
+    for (int e = 0; e < V && i + e < numelC; ++e) {
+      T v = in[i + e];
+      for (int s = 1; s < ns; ++s) v += in[(size_t)s * numelC + i + e];
+      out[i + e] = v;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_reduce(StepArgs a, SplitKArgs sk) {
   __shared__ double red[4];

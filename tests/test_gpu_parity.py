@@ -367,6 +367,8 @@ def test_launcher_retiles_by_replica_count():
     ("km,kn->mn", [(512, 128), (512, 128)]),            # 8 slabs (the reduce pass's 8 x 2 form)
     ("km,kn->mn", [(2304, 64), (2304, 64)]),            # 36 slabs: more than the unrolled forms take
     ("km,kn->mn", [(256, 65), (256, 33)]),              # odd element count: scalar reduce path
+    ("km,kn->mn", [(19200, 64), (19200, 64)]),          # 300 slabs: folded 16 to 1 twice (300 -> 19 -> 2)
+    ("km,kn->mn", [(2304, 65), (2304, 33)]),            # 36 slabs of an odd element count: scalar fold
 ])
 def test_latency_mode_split_k(dtype, tol, einstr, shapes):
     """One small network: 64 x 64 tiles with K split over workgroups and a fixed-order slab reduction,
