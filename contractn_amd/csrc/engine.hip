@@ -171,6 +171,12 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype) {
 template <typename T>
 static void launch_splitk_reduce(Exec* E, int partials, int R, const StepArgs& a, SplitKArgs sk);
 
+// Tiny output, huge K (CTN_KERNEL_DOT: at most 64 outputs): split K over workgroups as well, see k_dot_split
+static int dot_splits(const Step& st) {
+  if (st.kernel != CTN_KERNEL_DOT || st.K < 32768) return 0;
+  return (int)std::min<int64_t>(1024, st.K / 8192);
+}
+
 template <int MA>
 static void launch_sk_b(int mb, dim3 grid, hipStream_t st, const StepArgs& a, const SplitKArgs& sk) {
   switch (mb) {
@@ -442,6 +448,22 @@ static int exec_launch_steps(Exec* E) {
         break;
       }
       case CTN_KERNEL_DOT:
+        if (const int S0 = E->d_slab ? dot_splits(st) : 0) {
+          SplitKArgs sk{};
+          sk.slab = E->d_slab;
+          sk.numelC = P.tensors[st.out].numel;
+          sk.kchunk = (int32_t)(((st.K + S0 - 1) / S0 + 255) / 256 * 256);
+          sk.S = (int32_t)((st.K + sk.kchunk - 1) / sk.kchunk);
+          const dim3 g((unsigned)((int64_t)st.blocks * sk.S), R);
+          if (P.dtype == CTN_F32) {
+            hipLaunchKernelGGL(k_dot_split<float>, g, dim3(256), 0, E->stream, a, (float*)sk.slab, sk.numelC, sk.S, sk.kchunk);
+            launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
+          } else {
+            hipLaunchKernelGGL(k_dot_split<double>, g, dim3(256), 0, E->stream, a, (double*)sk.slab, sk.numelC, sk.S, sk.kchunk);
+            launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
+          }
+          break;
+        }
         if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_dot<float>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
         else hipLaunchKernelGGL(k_dot<double>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
         break;
@@ -708,13 +730,14 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   HIPCHECK_X(hipMalloc((void**)&E.d_scratch, (size_t)replicas * std::max<int64_t>(P.max_collapse_blocks, 1) * 8));
   {
     size_t slab_elems = 0;   // split-K scratch: S slabs shaped like the step's output, per replica
+    auto splits_of = [&](const Step& st) { const int S = splitk_splits(st, replicas, E.n_cu, P.dtype); return S ? S : dot_splits(st); };
     for (const Step& st : P.steps)
-      if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype))
+      if (const int S = splits_of(st))
         slab_elems = std::max(slab_elems, (size_t)S * (size_t)P.tensors[st.out].numel * (size_t)replicas);
     if (slab_elems) HIPCHECK_X(hipMalloc((void**)&E.d_slab, slab_elems * (P.dtype == CTN_F64 ? 8 : 4)));
     size_t fold_elems = 0;   // a step with more than 16 slabs folds them 16 to 1 into this buffer and back
     for (const Step& st : P.steps)
-      if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype))
+      if (const int S = splits_of(st))
         if (S > 16)
           fold_elems = std::max(fold_elems, (size_t)((S + 15) / 16) * (size_t)P.tensors[st.out].numel * (size_t)replicas);
     if (fold_elems) HIPCHECK_X(hipMalloc((void**)&E.d_slab2, fold_elems * (P.dtype == CTN_F64 ? 8 : 4)));
@@ -724,7 +747,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   for (int s = 0; s < P.n_steps; ++s) {
     const Step& st = P.steps[s];
     E.step_partials[s] = st.partials;
-    if (E.d_slab && splitk_splits(st, replicas, E.n_cu, P.dtype))
+    if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype) || dot_splits(st)))
       E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxPartials, P.tensors[st.out].numel / 1024));
   }
   HIPCHECK_X(hipMalloc((void**)&E.d_log, (size_t)replicas * 8));

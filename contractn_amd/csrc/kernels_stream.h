@@ -213,6 +213,41 @@ __global__ __launch_bounds__(256) void k_dot(StepArgs a) {
   }
 }
 
+// K-dot-split: the same outputs when K is huge (the inner product that closes a network: 1 output, 16.7 M
+// terms took one workgroup 36.7 ms): workgroup (o, s) sums k-range s of output o - raw products, four
+// independent chains per thread - into slab s of the split-K scratch (laid out like C); the split-K reduce
+// pass (k_splitk_fold / k_splitk_reduce) adds the slabs in a fixed order, rescales and emits the abs-sum.
+template <typename T>
+__global__ __launch_bounds__(256) void k_dot_split(StepArgs a, T* __restrict__ slab, int64_t numelC, int S, int kchunk) {
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const T* __restrict__ A = (const T*)tp[a.idA];
+  const T* __restrict__ B = (const T*)tp[a.idB];
+  const int o = blockIdx.x / S, s = blockIdx.x - o * S;
+  const int n = o % a.N;
+  const int q = o / a.N;
+  const int m = q % a.M;
+  const int b = q / a.M;
+  const T* pa = A + a.obA[b] + a.omA[m];
+  const T* pb = B + a.obB[b] + a.onB[n];
+  const int k0 = s * kchunk, k1 = min(a.K, k0 + kchunk);
+  T acc[4] = {0, 0, 0, 0};
+  int k = k0 + threadIdx.x;
+  for (; k + 768 < k1; k += 1024) {
+    T x[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { x[u] = pa[a.okA[k + 256 * u]]; y[u] = pb[a.okB[k + 256 * u]]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = fma(x[u], y[u], acc[u]);
+  }
+  for (; k < k1; k += 256) acc[0] = fma(pa[a.okA[k]], pb[a.okB[k]], acc[0]);
+  const double mine = ((double)acc[0] + (double)acc[1]) + ((double)acc[2] + (double)acc[3]);
+  const T tot = (T)block_sum(mine, red);
+  if (threadIdx.x == 0)
+    slab[((size_t)r * S + s) * numelC + a.obC[b] + a.omC[m] + a.onC[n]] = tot;
+}
+
 // Collapse > 64 per-workgroup partials into one, in a fixed order.
 __global__ __launch_bounds__(256) void k_collapse(const double* scratch, int blocks, double* part) {
   __shared__ double red[4];

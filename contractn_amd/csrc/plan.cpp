@@ -298,8 +298,11 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     const int64_t outs = st.Bt * st.M * st.N;
     // tile kernels: both free extents >= 32, or one long (>= 128) and the other at least 8 wide - a
     // mostly-masked MFMA tile still beats the streaming kernels by an order of magnitude there
+    // ... and so does a huge K against a few rows and columns (8 x 8 x 4,194,304: one mostly-masked 64 x 64 tile
+    // per K split streams both operands once - 64 separate dot products re-read them 8 times each)
     const bool tileable = st.K >= 8 && ((st.M >= 32 && st.N >= 32) || (st.M >= 128 && st.N >= 8) ||
-                                        (st.N >= 128 && st.M >= 8));
+                                        (st.N >= 128 && st.M >= 8) ||
+                                        (st.K >= 32768 && st.M >= 4 && st.N >= 4 && st.M * st.N >= 32));
     if (P.dtype == CTN_F32 && tileable) {
       st.kernel = CTN_KERNEL_MFMA_F32;
       // 64-wide column tiles when they cover N with less padding (e.g. N = 64, 192, 320)

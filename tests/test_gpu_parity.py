@@ -466,3 +466,30 @@ def test_two_stage_ring_variant(einstr, shapes, force_large_tiles, monkeypatch):
     E.clear_caches()
     t_ref, c_ref = contract(einstr, *ops, split_format=True)     # same k order per element: same bits as the 3-stage kernel
     assert np.array_equal(t_hat, t_ref) and float(c) == float(c_ref)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-12)])
+@pytest.mark.parametrize("einstr,shapes", [
+    ("abc,abc->", [(64, 64, 64), (64, 64, 64)]),          # the inner product that closes a network: 1 output, K = 262,144
+    ("ab,ba->", [(1000, 777), (777, 1000)]),              # K = 777,000 with one operand transposed (gathered k)
+    ("ka,kb->ab", [(100000, 8), (100000, 8)]),            # 64 outputs, K = 100,000
+    ("xk,xk->x", [(3, 40000), (3, 40000)]),               # batch label, 3 outputs
+])
+def test_huge_k_tiny_output_is_split_over_workgroups(dtype, tol, einstr, shapes):
+    """At most 64 outputs and K >= 32768: K is split over workgroups (k_dot_split) and the slabs are added by the
+    split-K reduce pass in a fixed order - same value as NumPy, same bits run to run, also inside a path."""
+    rng = np.random.default_rng(13)
+    ops = [rng.standard_normal(s).astype(dtype) for s in shapes]
+    t, c = contract(einstr, *ops, split_format=True)
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    terms = np.einsum(einstr, *[np.abs(o).astype(np.float64) for o in ops])
+    got = np.asarray(t, dtype=np.float64) * np.exp(float(c))
+    assert np.max(np.abs(got - ref)) <= tol * np.max(terms)      # a sum of zero-mean products: accuracy relative to its terms
+    t2, c2 = contract(einstr, *ops, split_format=True)
+    assert np.array_equal(t, t2) and float(c) == float(c2)
+    if einstr == "abc,abc->":                                        # fed by a rescaled intermediate: lazy rescale in the reduce pass
+        w = (rng.standard_normal((64, 64)) * 3).astype(dtype)
+        t3, c3 = contract("abd,dc,abc->", ops[0], w, ops[1], optimize=((0, 1), (0, 1)), split_format=True)
+        ref3 = np.einsum("abd,dc,abc->", ops[0].astype(np.float64), w.astype(np.float64), ops[1].astype(np.float64))
+        terms3 = np.einsum("abd,dc,abc->", *[np.abs(x).astype(np.float64) for x in (ops[0], w, ops[1])])
+        assert abs(float(t3) * np.exp(float(c3)) - ref3) <= tol * terms3
