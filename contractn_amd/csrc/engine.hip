@@ -171,6 +171,15 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype) {
 template <typename T>
 static void launch_splitk_reduce(Exec* E, int partials, int R, const StepArgs& a, SplitKArgs sk);
 
+// A streaming step with few output items and a long K (column sums, `ab,ab->b`: 4 workgroups walked K = 4096 one
+// element at a time - 1.7 ms for 67 MB): split K over workgroups, partial sums through the split-K reduce pass
+static int stream_splits(const Step& st, int R, int n_cu) {
+  if (st.kernel != CTN_KERNEL_ELEMENT || st.K < 1024 || st.collapse) return 0;
+  const int64_t wgs = (int64_t)st.blocks * R;
+  if (wgs >= 2LL * n_cu) return 0;
+  return (int)std::max<int64_t>(2, std::min<int64_t>(std::min<int64_t>(st.K / 128, 1024), (8LL * n_cu + wgs - 1) / wgs));
+}
+
 // Tiny output, huge K (CTN_KERNEL_DOT: at most 64 outputs): split K over workgroups as well, see k_dot_split
 static int dot_splits(const Step& st) {
   if (st.kernel != CTN_KERNEL_DOT || st.K < 32768) return 0;
@@ -280,6 +289,7 @@ static int exec_launch_steps(Exec* E) {
     a.R = R;
     a.c_vec = (st.cvec && (s + 1 < P.n_steps || E->outs_aligned16)) ? 1 : 0;
     a.dbg = nullptr;
+    a.ks_slab = nullptr; a.ks_numelC = 0; a.ks_S = 0; a.ks_chunk = 0;
     a.ohA = T + st.t.ohA; a.ohB = T + st.t.ohB; a.ohC = T + st.t.ohC;
     a.olA = T + st.t.olA; a.olB = T + st.t.olB; a.olC = T + st.t.olC;
     a.H = (int32_t)st.H; a.L = (int32_t)st.L; a.Nv = (int32_t)st.Nv;
@@ -480,7 +490,16 @@ static int exec_launch_steps(Exec* E) {
         const int64_t rows = st.H * st.L * (int64_t)R;
         const int u = (nq % 4 == 0 && st.K <= 16 && rows * (nq / 4) >= (1 << 20)) ? 4 : 1;
         a.dNq = make_fastdiv(nq / u);
-        const dim3 g(st.blocks, R), b(256);
+        const int ks = E->d_slab ? stream_splits(st, R, E->n_cu) : 0;
+        SplitKArgs sk{};
+        if (ks) {
+          sk.slab = E->d_slab;
+          sk.numelC = P.tensors[st.out].numel;
+          sk.kchunk = (int32_t)((st.K + ks - 1) / ks);
+          sk.S = (int32_t)((st.K + sk.kchunk - 1) / sk.kchunk);
+          a.ks_slab = sk.slab; a.ks_numelC = sk.numelC; a.ks_S = sk.S; a.ks_chunk = sk.kchunk;
+        }
+        const dim3 g(st.blocks, R, ks ? sk.S : 1), b(256);
 #define CTN_STREAM(TT, VV, UU) hipLaunchKernelGGL((k_stream<TT, VV, UU>), g, b, 0, E->stream, a)
         if (P.dtype == CTN_F32) {
           if (vw == 4) { if (u == 4) CTN_STREAM(float, 4, 4); else CTN_STREAM(float, 4, 1); }
@@ -490,6 +509,10 @@ static int exec_launch_steps(Exec* E) {
           else { if (u == 4) CTN_STREAM(double, 1, 4); else CTN_STREAM(double, 1, 1); }
         }
 #undef CTN_STREAM
+        if (ks) {
+          if (P.dtype == CTN_F32) launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
+          else launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
+        }
         break;
       }
     }
@@ -730,7 +753,11 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   HIPCHECK_X(hipMalloc((void**)&E.d_scratch, (size_t)replicas * std::max<int64_t>(P.max_collapse_blocks, 1) * 8));
   {
     size_t slab_elems = 0;   // split-K scratch: S slabs shaped like the step's output, per replica
-    auto splits_of = [&](const Step& st) { const int S = splitk_splits(st, replicas, E.n_cu, P.dtype); return S ? S : dot_splits(st); };
+    auto splits_of = [&](const Step& st) {
+      if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype)) return S;
+      if (const int S = dot_splits(st)) return S;
+      return stream_splits(st, replicas, E.n_cu);
+    };
     for (const Step& st : P.steps)
       if (const int S = splits_of(st))
         slab_elems = std::max(slab_elems, (size_t)S * (size_t)P.tensors[st.out].numel * (size_t)replicas);
@@ -747,7 +774,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   for (int s = 0; s < P.n_steps; ++s) {
     const Step& st = P.steps[s];
     E.step_partials[s] = st.partials;
-    if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype) || dot_splits(st)))
+    if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype) || dot_splits(st) || stream_splits(st, replicas, E.n_cu)))
       E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxPartials, P.tensors[st.out].numel / 1024));
   }
   HIPCHECK_X(hipMalloc((void**)&E.d_log, (size_t)replicas * 8));

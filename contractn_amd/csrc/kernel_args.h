@@ -54,6 +54,11 @@ struct StepArgs {
   int32_t H, L, Nv, sAn, sBn;
   FastDiv dNq, dL, dNv;  // divisors: vectors per row, lo extent, n extent
   unsigned long long* dbg;  // CTN_STAMPS builds only: 4 cycle stamps per MFMA tile (else unused, null)
+  // K split of a streaming step with few outputs and a long K (k_stream, blockIdx.z = split): raw partial sums
+  // go to slab s of the split-K scratch instead of C; 0 splits = the plain form
+  void* ks_slab;
+  int64_t ks_numelC;
+  int32_t ks_S, ks_chunk;
 };
 
 struct FinalArgs {

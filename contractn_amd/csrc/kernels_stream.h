@@ -48,7 +48,7 @@ __device__ __forceinline__ void load_vec(const T* __restrict__ p, int stride_n, 
 // 2U loads of an item are issued back to back before any arithmetic.
 template <typename T, int V, int U, bool DA, bool DB>
 __device__ __forceinline__ double stream_items(const StepArgs& a, const T* __restrict__ A, const T* __restrict__ B,
-                                               T* __restrict__ C, T sA, T sB) {
+                                               T* __restrict__ C, T sA, T sB, int kbeg = 0, int kend = -1) {
   const uint32_t nq_per = (uint32_t)((a.Nv + V - 1) / V);
   const uint32_t S = nq_per / U;                 // U divides nq_per (checked on the host)
   const uint32_t items = (uint32_t)a.H * (uint32_t)a.L * S;  // < 2^31
@@ -70,8 +70,8 @@ __device__ __forceinline__ double stream_items(const StepArgs& a, const T* __res
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < V; ++v) acc[u][v] = 0;
-    const int nk = kone ? 1 : a.K;
-    for (int k = 0; k < nk; ++k) {
+    const int nk = kone ? 1 : (kend >= 0 ? kend : a.K);
+    for (int k = kbeg; k < nk; ++k) {
       const int ka = kone ? 0 : a.okA[k], kb = kone ? 0 : a.okB[k];
       T av[U][V], bv[U][V];
 #pragma unroll
@@ -122,6 +122,12 @@ __global__ __launch_bounds__(256) void k_stream(StepArgs a) {
   const T* __restrict__ A = (const T*)tp[a.idA];
   const T* __restrict__ B = (const T*)tp[a.idB];
   T* __restrict__ C = (T*)tp[a.idC];
+  if (a.ks_S > 0) {   // K split (few outputs, long K): this workgroup's k-range, un-scaled, into its slab
+    const int s = blockIdx.z;
+    T* slab = (T*)a.ks_slab + ((size_t)r * a.ks_S + s) * a.ks_numelC;
+    (void)stream_items<T, V, U, false, false>(a, A, B, slab, (T)1, (T)1, s * a.ks_chunk, min(a.K, (s + 1) * a.ks_chunk));
+    return;
+  }
   // x / 1 == x exactly, so the division is skipped for network inputs and un-rescaled tensors
   const bool da = sA != (T)1, db = sB != (T)1;
   double absv;

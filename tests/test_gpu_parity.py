@@ -493,3 +493,31 @@ def test_huge_k_tiny_output_is_split_over_workgroups(dtype, tol, einstr, shapes)
         ref3 = np.einsum("abd,dc,abc->", ops[0].astype(np.float64), w.astype(np.float64), ops[1].astype(np.float64))
         terms3 = np.einsum("abd,dc,abc->", *[np.abs(x).astype(np.float64) for x in (ops[0], w, ops[1])])
         assert abs(float(t3) * np.exp(float(c3)) - ref3) <= tol * terms3
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-12)])
+@pytest.mark.parametrize("einstr,shapes", [
+    ("ab->b", [(2048, 512)]),                             # column sums: few outputs, long strided K
+    ("ab,ab->b", [(3000, 260), (3000, 260)]),             # the same with a product; K % splits != 0, 65 vectors
+    ("ab,cb->b", [(1500, 64), (7, 64)]),                  # K = (a, c) composite
+    ("xab,xab->xb", [(2, 1200, 36), (2, 1200, 36)]),      # batch label
+])
+def test_streaming_step_with_few_outputs_and_long_k_is_split(dtype, tol, einstr, shapes):
+    """A streaming (non-MFMA) step whose outputs fill only a few workgroups and whose K is long runs its K range
+    split over workgroups, partial sums through the split-K reduce pass: same value, same bits run to run, and
+    correct when an operand is a rescaled intermediate."""
+    rng = np.random.default_rng(19)
+    ops = [(rng.standard_normal(s) + 0.25).astype(dtype) for s in shapes]
+    t, c = contract(einstr, *ops, split_format=True)
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    terms = np.einsum(einstr, *[np.abs(o).astype(np.float64) for o in ops])
+    got = np.asarray(t, dtype=np.float64) * np.exp(float(c))
+    assert np.max(np.abs(got - ref) / terms) <= tol
+    t2, c2 = contract(einstr, *ops, split_format=True)
+    assert np.array_equal(t, t2) and float(c) == float(c2)
+    if einstr == "ab,ab->b":
+        w = (rng.standard_normal((260, 260)) * 2).astype(dtype)
+        t3, c3 = contract("ad,db,ab->b", ops[0], w, ops[1], optimize=((0, 1), (0, 1)), split_format=True)
+        ref3 = np.einsum("ad,db,ab->b", *[x.astype(np.float64) for x in (ops[0], w, ops[1])])
+        terms3 = np.einsum("ad,db,ab->b", *[np.abs(x).astype(np.float64) for x in (ops[0], w, ops[1])])
+        assert np.max(np.abs(np.asarray(t3, dtype=np.float64) * np.exp(float(c3)) - ref3) / terms3) <= tol
