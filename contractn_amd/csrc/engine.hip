@@ -174,10 +174,18 @@ static void launch_splitk_reduce(Exec* E, int partials, int R, const StepArgs& a
 // A streaming step with few output items and a long K (column sums, `ab,ab->b`: 4 workgroups walked K = 4096 one
 // element at a time - 1.7 ms for 67 MB): split K over workgroups, partial sums through the split-K reduce pass
 static int stream_splits(const Step& st, int R, int n_cu) {
-  if (st.kernel != CTN_KERNEL_ELEMENT || st.K < 1024 || st.collapse) return 0;
+  if (st.kernel != CTN_KERNEL_ELEMENT || st.K < 1024) return 0;
   const int64_t wgs = (int64_t)st.blocks * R;
   if (wgs >= 2LL * n_cu) return 0;
   return (int)std::max<int64_t>(2, std::min<int64_t>(std::min<int64_t>(st.K / 128, 1024), (8LL * n_cu + wgs - 1) / wgs));
+}
+
+// Row-dot steps (one wave per output) with few outputs and a long K: split K over workgroups too
+static int rowdot_splits(const Step& st, int R, int n_cu) {
+  if (st.kernel != CTN_KERNEL_ROWDOT || st.K < 4096) return 0;
+  const int64_t waves = st.H * st.L * st.Nv * (int64_t)R;
+  if (waves >= 16LL * n_cu) return 0;
+  return (int)std::max<int64_t>(2, std::min<int64_t>(std::min<int64_t>(st.K / 1024, 1024), (16LL * n_cu + waves - 1) / waves));
 }
 
 // Tiny output, huge K (CTN_KERNEL_DOT: at most 64 outputs): split K over workgroups as well, see k_dot_split
@@ -279,6 +287,7 @@ static int exec_launch_steps(Exec* E) {
     a.partC = st.collapse ? E->d_scratch : part_dst;
     a.partC_stride = st.collapse ? st.blocks : kMaxPartials;
     int collapse_blocks = st.blocks;   // partials written per replica when the step collapses (a launcher may retile)
+    bool reduced = false;              // a K-split streaming / row-dot step: its reduce pass wrote the partials itself
     a.min_norm = P.min_norm;
     a.Bt = (int32_t)st.Bt; a.M = (int32_t)st.M; a.N = (int32_t)st.N; a.K = (int32_t)st.K;
     a.idA = st.lhs; a.idB = st.rhs >= 0 ? st.rhs : E->n_tensors - 1; a.idC = st.out;
@@ -477,10 +486,26 @@ static int exec_launch_steps(Exec* E) {
         if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_dot<float>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
         else hipLaunchKernelGGL(k_dot<double>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
         break;
-      case CTN_KERNEL_ROWDOT:
-        if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_rowdot<float>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
-        else hipLaunchKernelGGL(k_rowdot<double>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
+      case CTN_KERNEL_ROWDOT: {
+        const int ks = E->d_slab ? rowdot_splits(st, R, E->n_cu) : 0;
+        SplitKArgs sk{};
+        if (ks) {
+          sk.slab = E->d_slab;
+          sk.numelC = P.tensors[st.out].numel;
+          sk.kchunk = (int32_t)(((st.K + ks - 1) / ks + 63) / 64 * 64);
+          sk.S = (int32_t)((st.K + sk.kchunk - 1) / sk.kchunk);
+          a.ks_slab = sk.slab; a.ks_numelC = sk.numelC; a.ks_S = sk.S; a.ks_chunk = sk.kchunk;
+        }
+        const dim3 g(st.blocks, R, ks ? sk.S : 1);
+        if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_rowdot<float>, g, dim3(256), 0, E->stream, a);
+        else hipLaunchKernelGGL(k_rowdot<double>, g, dim3(256), 0, E->stream, a);
+        if (ks) {
+          a.partC = part_dst; a.partC_stride = kMaxPartials; reduced = true;
+          if (P.dtype == CTN_F32) launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
+          else launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
+        }
         break;
+      }
       default: {
         // vector stores need a 16-byte aligned destination: the caller's final buffer may not be
         const int vw = (s + 1 == P.n_steps && !E->outs_aligned16) ? 1 : st.vecw;
@@ -510,13 +535,14 @@ static int exec_launch_steps(Exec* E) {
         }
 #undef CTN_STREAM
         if (ks) {
+          a.partC = part_dst; a.partC_stride = kMaxPartials; reduced = true;
           if (P.dtype == CTN_F32) launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
           else launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
         }
         break;
       }
     }
-    if (st.collapse)
+    if (st.collapse && !reduced)
       hipLaunchKernelGGL(k_collapse, dim3(R), dim3(256), 0, E->stream, (const double*)E->d_scratch, collapse_blocks, part_dst);
     if (timed) HIPCHECK(hipEventRecord(E->events[ev0 + 1], E->stream));
   }
@@ -756,7 +782,8 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     auto splits_of = [&](const Step& st) {
       if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype)) return S;
       if (const int S = dot_splits(st)) return S;
-      return stream_splits(st, replicas, E.n_cu);
+      if (const int S = stream_splits(st, replicas, E.n_cu)) return S;
+      return rowdot_splits(st, replicas, E.n_cu);
     };
     for (const Step& st : P.steps)
       if (const int S = splits_of(st))
@@ -774,7 +801,8 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   for (int s = 0; s < P.n_steps; ++s) {
     const Step& st = P.steps[s];
     E.step_partials[s] = st.partials;
-    if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype) || dot_splits(st) || stream_splits(st, replicas, E.n_cu)))
+    if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
+                     rowdot_splits(st, replicas, E.n_cu)))
       E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxPartials, P.tensors[st.out].numel / 1024));
   }
   HIPCHECK_X(hipMalloc((void**)&E.d_log, (size_t)replicas * 8));

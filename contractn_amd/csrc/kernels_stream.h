@@ -156,6 +156,37 @@ __global__ __launch_bounds__(256) void k_rowdot(StepArgs a) {
   T* __restrict__ C = (T*)tp[a.idC];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t outs = (uint32_t)a.H * (uint32_t)a.L * (uint32_t)a.Nv;
+  if (a.ks_S > 0) {
+    // K split (few outputs, each with a long K: 100 x 4,194,304 took 100 waves 29.9 ms): blockIdx.z = k-range, raw
+    // partial sums into slab s (laid out like C), four independent chains per lane; the split-K reduce pass adds
+    // the slabs in a fixed order, rescales and emits the abs-sum
+    const int s = blockIdx.z;
+    T* __restrict__ slab = (T*)a.ks_slab + ((size_t)r * a.ks_S + s) * a.ks_numelC;
+    const int k0 = s * a.ks_chunk, k1 = min(a.K, k0 + a.ks_chunk);
+    for (uint32_t o = blockIdx.x * 4u + w; o < outs; o += gridDim.x * 4u) {
+      const uint32_t o2 = a.dNv.div(o);
+      const int n = (int)(o - o2 * (uint32_t)a.Nv);
+      const int h = (int)a.dL.div(o2);
+      const int l = (int)(o2 - (uint32_t)h * (uint32_t)a.L);
+      const T* pa = A + a.ohA[h] + a.olA[l] + (int64_t)n * a.sAn;
+      const T* pb = B + a.ohB[h] + a.olB[l] + (int64_t)n * a.sBn;
+      T acc[4] = {0, 0, 0, 0};
+      int k = k0 + lane;
+      for (; k + 192 < k1; k += 256) {
+        T x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { x[u] = pa[a.okA[k + 64 * u]]; y[u] = pb[a.okB[k + 64 * u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = fma(x[u], y[u], acc[u]);
+      }
+      for (; k < k1; k += 64) acc[0] = fma(pa[a.okA[k]], pb[a.okB[k]], acc[0]);
+      double v = ((double)acc[0] + (double)acc[1]) + ((double)acc[2] + (double)acc[3]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) slab[a.ohC[h] + a.olC[l] + n] = (T)v;
+    }
+    return;
+  }
   double mine = 0;
   for (uint32_t o = blockIdx.x * 4u + w; o < outs; o += gridDim.x * 4u) {  // wave-uniform
     const uint32_t o2 = a.dNv.div(o);

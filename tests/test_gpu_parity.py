@@ -521,3 +521,25 @@ def test_streaming_step_with_few_outputs_and_long_k_is_split(dtype, tol, einstr,
         ref3 = np.einsum("ad,db,ab->b", *[x.astype(np.float64) for x in (ops[0], w, ops[1])])
         terms3 = np.einsum("ad,db,ab->b", *[np.abs(x).astype(np.float64) for x in (ops[0], w, ops[1])])
         assert np.max(np.abs(np.asarray(t3, dtype=np.float64) * np.exp(float(c3)) - ref3) / terms3) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-12)])
+@pytest.mark.parametrize("einstr,shapes", [
+    ("ab,b->a", [(100, 40000), (40000,)]),                # GEMV with few rows: 100 waves would each walk 40,000 terms
+    ("ab,ab->a", [(300, 8200), (300, 8200)]),             # more than 64 workgroups' worth of outputs (collapse-mode partials)
+    ("abc,bc->a", [(70, 64, 128), (64, 128)]),            # composite K
+    ("xab,xb->xa", [(2, 90, 5000), (2, 5000)]),           # batch label
+])
+def test_row_dot_step_with_few_outputs_and_long_k_is_split(dtype, tol, einstr, shapes):
+    """Row-dot steps (one wave per output, lanes along a unit-stride K) with too few outputs to fill the chip split
+    their K range over workgroups as well (partial sums through the split-K reduce pass)."""
+    rng = np.random.default_rng(23)
+    ops = [(rng.standard_normal(s) + 0.25).astype(dtype) for s in shapes]
+    t, c = contract(einstr, *ops, split_format=True)
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    terms = np.einsum(einstr, *[np.abs(o).astype(np.float64) for o in ops])
+    got = np.asarray(t, dtype=np.float64) * np.exp(float(c))
+    assert np.max(np.abs(got - ref) / terms) <= tol
+    assert abs(np.mean(np.abs(t)) - 1.0) < (1e-5 if dtype == np.float32 else 1e-13)     # the abs-sum partials are right
+    t2, c2 = contract(einstr, *ops, split_format=True)
+    assert np.array_equal(t, t2) and float(c) == float(c2)
