@@ -174,7 +174,7 @@ static void launch_splitk_reduce(Exec* E, int partials, int R, const StepArgs& a
 // A streaming step with few output items and a long K (column sums, `ab,ab->b`: 4 workgroups walked K = 4096 one
 // element at a time - 1.7 ms for 67 MB): split K over workgroups, partial sums through the split-K reduce pass
 static int stream_splits(const Step& st, int R, int n_cu) {
-  if (st.kernel != CTN_KERNEL_ELEMENT || st.K < 1024) return 0;
+  if (st.kernel != CTN_KERNEL_ELEMENT || st.K < 1024 || st.kvec) return 0;
   const int64_t wgs = (int64_t)st.blocks * R;
   if (wgs >= 2LL * n_cu) return 0;
   return (int)std::max<int64_t>(2, std::min<int64_t>(std::min<int64_t>(st.K / 128, 1024), (8LL * n_cu + wgs - 1) / wgs));
@@ -507,6 +507,12 @@ static int exec_launch_steps(Exec* E) {
         break;
       }
       default: {
+        if (st.kvec) {   // short unit-stride K of the left operand: one output per thread, 16-byte loads along k
+          a.dNv = make_fastdiv(st.Nv);
+          if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_stream_kvec<float>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
+          else hipLaunchKernelGGL(k_stream_kvec<double>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
+          break;
+        }
         // vector stores need a 16-byte aligned destination: the caller's final buffer may not be
         const int vw = (s + 1 == P.n_steps && !E->outs_aligned16) ? 1 : st.vecw;
         const int64_t nq = (st.Nv + vw - 1) / vw;

@@ -140,6 +140,52 @@ __global__ __launch_bounds__(256) void k_stream(StepArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// K-stream-kvec: the left operand is unit-stride along a short K (4 .. 64 elements) while the output's unit-stride
+// index strides it (`abk,k->ab`, a vector or small tensor applied to the innermost leg): one output per thread, its
+// K operand elements fetched as 16-byte vectors (adjacent threads read adjacent K-runs), the other operand through
+// its k table (small: cache hits).  Same operations in the same order as k_stream (divide on load, fma over
+// ascending k), so the results are bit-identical to it.  4096 x 4096 x 16: 2.4 ms -> see DESIGN.md.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_stream_kvec(StepArgs a) {
+  constexpr int V = 16 / sizeof(T);
+  typedef typename VecOf<T, V>::type VT;
+  __shared__ double red[4];
+  const int r = blockIdx.y;
+  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const bool da = sA != (T)1, db = sB != (T)1;
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const T* __restrict__ A = (const T*)tp[a.idA];
+  const T* __restrict__ B = (const T*)tp[a.idB];
+  T* __restrict__ C = (T*)tp[a.idC];
+  const uint32_t outs = (uint32_t)a.H * (uint32_t)a.L * (uint32_t)a.Nv;
+  double absv = 0;
+  for (uint32_t o = blockIdx.x * 256u + threadIdx.x; o < outs; o += gridDim.x * 256u) {
+    const uint32_t row = a.dNv.div(o);
+    const int n = (int)(o - row * (uint32_t)a.Nv);
+    const int h = (int)a.dL.div(row);
+    const int l = (int)(row - (uint32_t)h * (uint32_t)a.L);
+    const T* pa = A + a.ohA[h] + a.olA[l] + (int64_t)n * a.sAn;
+    const T* pb = B + a.ohB[h] + a.olB[l] + (int64_t)n * a.sBn;
+    T acc = 0;
+    for (int k = 0; k < a.K; k += V) {
+      const VT xv = *reinterpret_cast<const VT*>(pa + k);
+      const T* x = reinterpret_cast<const T*>(&xv);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const T y = pb[a.okB[k + v]];
+        acc = fma(da ? x[v] / sA : x[v], db ? y / sB : y, acc);
+      }
+    }
+    C[(size_t)row * a.Nv + n] = acc;
+    absv += (double)fabs(acc);
+  }
+  const double tot = block_sum(absv, red);
+  if (threadIdx.x == 0) a.partC[(size_t)r * a.partC_stride + blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------
 // K-rowdot: one WAVE per output element, the 64 lanes stride a unit-stride K (coalesced
 // 256-byte reads), xor-butterfly reduction.  GEMV / batched-dot shaped steps.
 // ---------------------------------------------------------------------------

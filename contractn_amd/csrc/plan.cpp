@@ -377,7 +377,21 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
         const LabelInfo* kl = G[kK].back();
         kUnit = aBig ? (kl->inA && kl->sA == 1) : (kl->inB && kl->sB == 1);
       }
-      if (st.K >= 256 && kUnit) {
+      // a SHORT unit-stride K of the left operand under a strided output index (`abk,k->ab`: a vector applied to the
+      // innermost leg): one output per thread, the operand's K elements as 16-byte loads (k_stream_kvec) - with
+      // vectors along n instead every element is its own 4-byte gather
+      bool kv = rhs >= 0 && G[kK].size() == 1 && st.K >= (int64_t)vec && st.K <= 64 && st.K % vec == 0 && st.sAn != 1;
+      if (kv) {
+        const LabelInfo* kl = G[kK][0];
+        if (!(kl->inA && kl->sA == 1 && kl->inB)) kv = false;
+        for (auto& l : info) if (&l != kl && l.inA && l.sA % vec != 0) kv = false;
+      }
+      if (kv) {
+        st.kernel = CTN_KERNEL_ELEMENT;
+        st.kvec = 1;
+        st.vecw = 1;
+        st.blocks = (int)std::min<int64_t>((st.H * st.L * st.Nv + 255) / 256, kStreamMaxBlocks);
+      } else if (st.K >= 256 && kUnit) {
         st.kernel = CTN_KERNEL_ROWDOT;
         // persistent-style grid: at most 16 workgroups per CU, waves stride over the outputs
         st.blocks = (int)std::min<int64_t>((outs + 3) / 4, kStreamMaxBlocks);

@@ -55,6 +55,7 @@ struct Step {
   // n runs along C's unit-stride label, sAn/sBn are the operands' strides along it (0 = broadcast)
   int64_t H = 1, L = 1, Nv = 1, sAn = 0, sBn = 0;
   int vecw = 1;          // output elements per thread (16-byte vectors when > 1)
+  int kvec = 0;          // streaming step whose left operand is unit-stride along a short K: 16-byte loads along k
   bool chain_ok = false; // small enough for the persistent chain walker
   int tileN = kTileN;    // MFMA f32 column tile: 128, or 64 when that wastes less padding
   int tileM = kTileM;    // MFMA f32 row tile: 128, or 256 = the large-tile LDS-DMA kernel (kernels_mfma_g.h)

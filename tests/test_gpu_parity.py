@@ -543,3 +543,29 @@ def test_row_dot_step_with_few_outputs_and_long_k_is_split(dtype, tol, einstr, s
     assert abs(np.mean(np.abs(t)) - 1.0) < (1e-5 if dtype == np.float32 else 1e-13)     # the abs-sum partials are right
     t2, c2 = contract(einstr, *ops, split_format=True)
     assert np.array_equal(t, t2) and float(c) == float(c2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-12)])
+@pytest.mark.parametrize("einstr,shapes", [
+    ("abk,k->ab", [(37, 44, 16), (16,)]),                 # a vector applied to the innermost leg
+    ("abk,ck->abc", [(20, 12, 8), (3, 8)]),               # a small matrix: output index c comes from the other operand
+    ("xak,xk->xa", [(5, 300, 12), (5, 12)]),              # batch label
+    ("abk,bk->ab", [(64, 40, 64), (40, 64)]),             # K = 64, second operand indexed by an output label
+    ("akb,k->ab", [(33, 16, 8), (16,)]),                  # NOT this kernel (K strided in the operand): the generic path
+])
+def test_short_contiguous_k_under_a_strided_output_index(dtype, tol, einstr, shapes):
+    """k_stream_kvec: same results as NumPy, and as a step fed by a rescaled intermediate."""
+    rng = np.random.default_rng(29)
+    ops = [(rng.standard_normal(s) + 0.25).astype(dtype) for s in shapes]
+    t, c = contract(einstr, *ops, split_format=True)
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    terms = np.einsum(einstr, *[np.abs(o).astype(np.float64) for o in ops])
+    got = np.asarray(t, dtype=np.float64) * np.exp(float(c))
+    assert np.max(np.abs(got - ref) / terms) <= tol
+    assert abs(np.mean(np.abs(t)) - 1.0) < (1e-5 if dtype == np.float32 else 1e-13)
+    if einstr == "abk,k->ab":
+        w = (rng.standard_normal((16, 16)) * 2).astype(dtype)
+        t3, c3 = contract("abj,jk,k->ab", ops[0], w, ops[1], optimize=((0, 1), (0, 1)), split_format=True)
+        ref3 = np.einsum("abj,jk,k->ab", *[x.astype(np.float64) for x in (ops[0], w, ops[1])])
+        terms3 = np.einsum("abj,jk,k->ab", *[np.abs(x).astype(np.float64) for x in (ops[0], w, ops[1])])
+        assert np.max(np.abs(np.asarray(t3, dtype=np.float64) * np.exp(float(c3)) - ref3) / terms3) <= tol
