@@ -53,14 +53,18 @@ typedef enum { CTN_MEM_HOST = 0, CTN_MEM_DEVICE = 1 } ctn_memspace;
 /* which kernel family a step was lowered to (ctn_step_info.kernel) */
 typedef enum {
   CTN_KERNEL_ELEMENT = 0, /* streaming gather-multiply: one thread per 16-byte output vector, K loop
-                             (copy-tensor / hyperedge products, Khatri-Rao, traces, small-K steps) */
-  CTN_KERNEL_DOT = 1,     /* one workgroup per output element, K split over lanes */
+                             (copy-tensor / hyperedge products, Khatri-Rao, traces, small-K steps); one output per
+                             thread with 16-byte loads along a short unit-stride K; K split over workgroups
+                             (slabs + fixed-order reduce) when the outputs are few and K is long */
+  CTN_KERNEL_DOT = 1,     /* one workgroup per output element, K split over lanes - and over workgroups from
+                             K = 32768 on (slabs + fixed-order reduce) */
   CTN_KERNEL_MFMA_F32 = 2,/* 128x128 / 128x64 LDS-tiled v_mfma_f32_32x32x2_f32 GEMM, gather loads;
                              256x128 tiles fed by LDS-DMA when every tile is full (tile_m = 256);
                              64x64 split-K form when a launch cannot fill the chip */
   CTN_KERNEL_MFMA_F64 = 3,/* 128x64 LDS-tiled v_mfma_f64_16x16x4_f64 GEMM, gather loads; 128x128 tiles fed by
                              LDS-DMA (tile_n = 128); 64x64 split-K form for small launches */
-  CTN_KERNEL_ROWDOT = 4   /* one wave per output element, lanes along a unit-stride K (GEMV-like) */
+  CTN_KERNEL_ROWDOT = 4   /* one wave per output element, lanes along a unit-stride K (GEMV-like); K split over
+                             workgroups as well when the outputs are few */
 } ctn_kernel_kind;
 
 typedef struct ctn_plan ctn_plan;
