@@ -569,3 +569,22 @@ def test_short_contiguous_k_under_a_strided_output_index(dtype, tol, einstr, sha
         ref3 = np.einsum("abj,jk,k->ab", *[x.astype(np.float64) for x in (ops[0], w, ops[1])])
         terms3 = np.einsum("abj,jk,k->ab", *[np.abs(x).astype(np.float64) for x in (ops[0], w, ops[1])])
         assert np.max(np.abs(np.asarray(t3, dtype=np.float64) * np.exp(float(c3)) - ref3) / terms3) <= tol
+
+
+def test_k_split_forms_with_replicas_in_flight():
+    """The K-split forms with three replicas per launch: every replica (different data) against NumPy."""
+    cases = [("abc,abc->", [(64, 64, 64), (64, 64, 64)]), ("ab,b->a", [(100, 40000), (40000,)]),
+             ("ab,ab->a", [(300, 8200), (300, 8200)]), ("ab->b", [(2048, 512)]),
+             ("km,kn->mn", [(19200, 64), (19200, 64)]), ("ka,kb->ab", [(100000, 8), (100000, 8)])]
+    for dtype, tol in ((np.float32, 2e-5), (np.float64, 1e-12)):
+        for ein, shapes in cases:
+            rng = np.random.default_rng(5)
+            sets = [[(rng.standard_normal(s) + 0.25).astype(dtype) * (r + 1) for s in shapes] for r in range(3)]
+            bc = E.BatchedContraction(ein, shapes, dtype, optimize=((0, 1),) if len(shapes) == 2 else ((0,),), replicas=3)
+            t, c = bc.run_host(sets)
+            bc.executor.close()
+            for r in range(3):
+                ref = np.einsum(ein, *[o.astype(np.float64) for o in sets[r]])
+                terms = np.einsum(ein, *[np.abs(o).astype(np.float64) for o in sets[r]])
+                got = np.asarray(t[r], dtype=np.float64) * np.exp(float(c[r]))
+                assert np.max(np.abs(got - ref) / terms) <= tol, (ein, np.dtype(dtype).name, r)
