@@ -309,9 +309,13 @@ def _random_greedy(term_sets, out, sizes, repeats=32, seed=0, memory_limit=None,
                     refs[s_] = refs.get(s_, 0) + 1
                     owners.setdefault(s_, []).append(pos)
             pairs = set()
-            for who in owners.values():
-                if len(who) > 1:
+            for lab, who in owners.items():      # pairs that share a label which can be summed (not an output / batch
+                if len(who) > 1 and lab not in out_set:   # label: on a batch hyperedge that alone is O(n^2) pairs)
                     pairs.update(itertools.combinations(who, 2))
+            if not pairs:
+                for who in owners.values():
+                    if len(who) > 1:
+                        pairs.update(itertools.combinations(who, 2))
             if not pairs:
                 order = sorted(range(len(live)), key=lambda p_: (_size(live[p_], sizes), p_))
                 pairs = {tuple(sorted(order[:2]))}
@@ -340,6 +344,66 @@ def _random_greedy(term_sets, out, sizes, repeats=32, seed=0, memory_limit=None,
             seen.add(key)
             ranked.append(path)
     return ranked[:keep]
+
+
+def _cluster_greedy(term_sets, out, sizes, seed=0, bound=None):
+    """Grow ONE cluster from operand ``seed``: repeatedly absorb the connected operand whose absorption is
+    cheapest (joint index space, then result size).  On chains and lattices this is a boundary sweep - the MPS
+    zipper, the PEPS row sweep, the left-to-right walk of a chain that hangs on a batch hyperedge - which the
+    pairwise greedy scores miss when merging two small neighbours looks cheaper locally."""
+    n = len(term_sets)
+    out_set = set(out)
+    refs = {}
+    for t in term_sets:
+        for lab in t:
+            refs[lab] = refs.get(lab, 0) + 1
+    remaining = set(range(n)) - {seed}
+    cluster, cid = set(term_sets[seed]), seed
+    pairs, next_id = [], n
+    inside = {lab: 1 for lab in term_sets[seed]}      # how many absorbed operands carry each label
+    spent = 0
+    while remaining:
+        # connected through a label that can be summed first; an output (batch) label alone connects everything
+        cands = ([t for t in remaining if (term_sets[t] & cluster) - out_set] or
+                 [t for t in remaining if term_sets[t] & cluster] or list(remaining))
+        best = None
+        for t in cands:
+            joint = cluster | term_sets[t]
+            new = {lab for lab in joint if lab in out_set or refs[lab] - inside.get(lab, 0) - (lab in term_sets[t]) > 0}
+            key = (_size(joint, sizes), _size(new, sizes), t)
+            if best is None or key < best[0]:
+                best = (key, t, new)
+        key, t, new = best
+        spent += key[0]
+        if bound is not None and spent > bound:
+            return None
+        for lab in term_sets[t]:
+            inside[lab] = inside.get(lab, 0) + 1
+        pairs.append((cid, t))
+        cid, next_id = next_id, next_id + 1
+        cluster = new
+        remaining.discard(t)
+    return _ssa_pairs_to_linear(pairs, n)
+
+
+def _best_cluster_sweep(term_sets, out, sizes, bound=None):
+    """`_cluster_greedy` from a handful of seeds (both ends, the middle, the smallest and the largest operand);
+    the cheapest sweep, or None when none stays under ``bound``."""
+    n = len(term_sets)
+    by_size = sorted(range(n), key=lambda i: (_size(term_sets[i], sizes), i))
+    seeds = []
+    for sd in (0, n - 1, n // 2, by_size[0], by_size[-1], n // 4, (3 * n) // 4):
+        if sd not in seeds:
+            seeds.append(sd)
+    best = None
+    for sd in seeds:
+        p = _cluster_greedy(term_sets, out, sizes, sd, bound=bound if best is None else min(bound or best[0][0], best[0][0]))
+        if p is None:
+            continue
+        key = path_cost(term_sets, out, sizes, p)
+        if best is None or key < best[0]:
+            best = (key, p)
+    return None if best is None else best[1]
 
 
 def _reconfigure(term_sets, out, sizes, path, max_leaves=8, rounds=8, memory_limit=None):
@@ -502,6 +566,14 @@ def find_path(terms, out, sizes, optimize, memory_limit=None):
             biggest_in = max((_size(t, sizes) for t in sets), default=1)
             if not hq and path_cost(sets, out, sizes, path)[1] <= biggest_in:
                 return path
+            # a second kind of start: the best single-cluster sweep (boundary sweeps of chains and lattices); anything
+            # costing more than 100 x the pairwise result is a blown-up seed and is dropped on the way
+            sweep = _best_cluster_sweep(sets, out, sizes, bound=100 * path_cost(sets, out, sizes, path)[0])
+            if sweep is not None:
+                starts = list(starts) + [sweep]
+            # refining a start that is several times dearer than the best one rarely catches up: keep those within 3 x
+            costs = [path_cost(sets, out, sizes, st)[0] for st in starts]
+            starts = [st for st, c in zip(starts, costs) if c <= 3 * min(costs)]
             # the refinement is a local search on a rugged landscape: the best start is not always the best finish,
             # so auto-hq refines its four best trials and keeps the cheapest result (auto: the best trial only)
             better = min((_reconfigure(sets, out, sizes, st, max_leaves=10 if hq else (8 if n <= 256 else 6),
