@@ -203,3 +203,34 @@ def test_auto_on_a_lattice_beats_the_row_sweep():
     greedy = paths.path_cost(sets, out, sizes, paths.find_path(terms, out, sizes, "greedy"))
     assert auto[0] < row[0] < greedy[0]
     assert auto[1] <= row[1]
+
+
+def test_auto_finds_the_sweep_of_a_chain_on_a_batch_hyperedge():
+    """BASELINE config 3b in small: an MPS whose every site also takes a batched input through one batch label.
+    Pairwise greedy merges cores (or batch inputs); the single-cluster start walks the chain - `auto` must end at
+    (or below) the hand-written left-to-right sweep."""
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+
+    class Shape:
+        def __init__(self, shape):
+            self.shape, self.ndim = tuple(shape), len(shape)
+
+    batch, n_sites, bond, phys = 512, 20, 32, 4
+    tn = TN()
+    hub = tn.add_copy_node(n_sites + 1)
+    cores = [Shape((phys, bond) if i in (0, n_sites - 1) else (phys, bond, bond)) for i in range(n_sites)]
+    nodes = nets.add_mps(tn, cores)
+    for i, node in enumerate(nodes):
+        inp = tn.add_input_node((batch, phys), var_shape_axes=(0,))
+        tn.connect_nodes(inp, node, 1, 0)
+        tn.connect_nodes(hub, inp, i, 0)
+    shapes = [c.shape for c in cores] + [(batch, phys)] * n_sites
+    terms, out, sizes = paths.parse_einsum_input(tn.einsum_str, shapes)
+    sets = [set(t) for t in terms]
+    hand = paths.path_cost(sets, out, sizes, ssa_to_linear(nets.batched_mps_path(n_sites), 2 * n_sites))
+    auto = paths.path_cost(sets, out, sizes, paths.find_path(terms, out, sizes, "auto"))
+    greedy = paths.path_cost(sets, out, sizes, paths.find_path(terms, out, sizes, "greedy"))
+    assert auto[0] <= hand[0] * 1.05 and auto[1] <= hand[1]
+    assert greedy[0] > 2 * hand[0]          # what the start from pairwise greedy alone would have given
