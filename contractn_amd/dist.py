@@ -41,24 +41,24 @@ def choose_slices_with_path(einstr, shapes, min_slices=1, max_intermediate=None,
     terms, out, sizes = paths.parse_einsum_input(einstr, shapes)
     sets = [set(t) for t in terms]
 
-    def search(sz, current=None):
-        # candidates: the path in hand refined for the new sizes (so a step never loses what it had), a fresh
-        # search, and noisy restarts of it
-        cands = []
-        if current is not None:
-            cands.append(paths._reconfigure(sets, out, sz, current, max_leaves=8, rounds=8))
+    def search(sz, pool=()):
+        # candidates: every path in hand refined for the new sizes (so a step never loses what it had), a fresh
+        # search, and refined noisy-greedy trees (a different basin than the fresh search's cluster sweep)
+        cands = [paths._reconfigure(sets, out, sz, p, max_leaves=8, rounds=8) for p in pool]
         cands.append(paths.find_path(terms, out, sz, optimize))
-        for t in range(1, trials):
+        for t in range(trials):
             cands.append(paths._reconfigure(sets, out, sz, paths._random_greedy(sets, out, sz, repeats=4, seed=t),
                                             max_leaves=8, rounds=8))
-        best = None
-        for p in cands:
+        ranked, seen = [], set()
+        for p in sorted(cands, key=lambda q: paths.path_cost(sets, out, sz, q)):
             key = paths.path_cost(sets, out, sz, p)
-            if best is None or key < best[0]:
-                best = (key, p)
-        return best
+            if key not in seen:
+                seen.add(key)
+                ranked.append(p)
+        return paths.path_cost(sets, out, sz, ranked[0]), ranked[:3]
 
-    (base_flops, base_big), path = search(sizes)
+    (base_flops, base_big), pool = search(sizes)
+    path = pool[0]
     sz, count, chosen = dict(sizes), 1, []
     flops, big = base_flops, base_big
     while (count < min_slices or (max_intermediate is not None and big > max_intermediate)) and len(chosen) < max_labels:
@@ -68,7 +68,8 @@ def choose_slices_with_path(einstr, shapes, min_slices=1, max_intermediate=None,
                 continue
             s2 = dict(sz)
             s2[lab] = 1
-            f, b = paths.path_cost(sets, out, s2, path)
+            # the label's efficiency on the best of the paths in hand
+            f, b = min(paths.path_cost(sets, out, s2, p) for p in pool)
             eff = math.log(max(f * sizes[lab], 1) / max(flops, 1)) / math.log(sizes[lab])
             key = (eff, b, lab)
             if best is None or key < best[0]:
@@ -79,7 +80,8 @@ def choose_slices_with_path(einstr, shapes, min_slices=1, max_intermediate=None,
         chosen.append(lab)
         sz[lab] = 1
         count *= sizes[lab]
-        (flops, big), path = search(sz, path)
+        (flops, big), pool = search(sz, pool)
+        path = pool[0]
     # the path indexes the operands of the sliced network, which are the same operands in the same order
     report = {"slices": count, "largest_intermediate": big, "unsliced_largest_intermediate": base_big,
               "work_overhead": flops * count / max(base_flops, 1), "unsliced_flops": base_flops}
