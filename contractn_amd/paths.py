@@ -179,6 +179,36 @@ def path_cost(term_sets, out, sizes, path):
     return flops, biggest
 
 
+def path_time_model(term_sets, out, sizes, path, elem_bytes=4):
+    """Rough device time of a path in microseconds, for choosing between candidate paths of similar multiply-add
+    counts: per step the larger of (tile-padded multiply-adds at 60 T/s: rows to 128, columns to 64) and (operand
+    and result bytes at 3 TB/s), plus 6 us of launch.  Constants are MI355X fp32 orders of magnitude."""
+    live = [set(t) for t in term_sets]
+    out_set = set(out)
+    total = 0.0
+    for step in path:
+        step = tuple(sorted(step))
+        if len(step) == 1:
+            continue
+        i, j = step
+        a, b = live[i], live[j]
+        rest = [x for k, x in enumerate(live) if k not in (i, j)]
+        new, _ = _pair_result(a, b, rest, out)
+        batch = _size(a & b & new, sizes)
+        m = _size((a - b) & new, sizes)
+        n = _size((b - a) & new, sizes)
+        k = _size((a | b) - new, sizes)
+        if m < n:
+            m, n = n, m
+        pm = -(-m // 128) * 128 if m > 32 else m
+        pn = -(-n // 64) * 64 if n > 8 else n
+        mac_us = batch * pm * pn * k / 60e6
+        mem_us = elem_bytes * (_size(a, sizes) + _size(b, sizes) + _size(new, sizes)) / 3e6
+        total += max(mac_us, mem_us) + 6.0
+        live = rest + [new]
+    return total
+
+
 def path_profile(term_sets, out, sizes, path):
     """(flop proxy, list of every intermediate's element count) of a path."""
     live = [set(t) for t in term_sets]
@@ -575,10 +605,11 @@ def find_path(terms, out, sizes, optimize, memory_limit=None):
             costs = [path_cost(sets, out, sizes, st)[0] for st in starts]
             starts = [st for st, c in zip(starts, costs) if c <= 3 * min(costs)]
             # the refinement is a local search on a rugged landscape: the best start is not always the best finish,
-            # so auto-hq refines its four best trials and keeps the cheapest result (auto: the best trial only)
+            # so every start that is left is refined and the result with the least MODELLED DEVICE TIME is kept
+            # (`path_time_model`: tile padding, bytes and launches, not multiply-adds alone)
             better = min((_reconfigure(sets, out, sizes, st, max_leaves=10 if hq else (8 if n <= 256 else 6),
                                        rounds=12 if hq else 8, memory_limit=memory_limit) for st in starts),
-                         key=lambda q: path_cost(sets, out, sizes, q))
+                         key=lambda q: (path_time_model(sets, out, sizes, q), path_cost(sets, out, sizes, q)))
             # fewer flops must not buy an intermediate the engine cannot hold (2^31 elements) when the start fits
             if path_cost(sets, out, sizes, better)[1] >= (1 << 31) > path_cost(sets, out, sizes, path)[1]:
                 return path
