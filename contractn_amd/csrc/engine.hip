@@ -49,6 +49,19 @@ thread_local std::string g_err;
     }                                                                                    \
   } while (0)
 
+// Entry points select the executor's device and give the caller's current device back on return (a caller
+// that works on another GPU - torch.cuda.current_device() - must not find it changed behind its back).
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+    err = prev == dev ? hipSuccess : hipSetDevice(dev);
+    if (prev == dev) prev = -1;   // nothing to restore
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct Exec {
   const Plan* plan = nullptr;
   int device = 0;
@@ -90,12 +103,21 @@ struct Exec {
   double* d_stepNumel = nullptr;
   char* d_stage_in = nullptr;
   char* d_stage_out = nullptr;
+  // Rescale mode.  false = lazy (default): tile kernels multiply by 1 / (sA sB) in the epilogue, the
+  // un-normalised tensor is what is stored.  true = eager: every intermediate is normalised in place right
+  // after its step (k_renorm) and consumed with scale 1 - the reference's own order of operations.  An executor
+  // switches to eager by itself, and repeats the contraction, when the scale registers of a finished run show
+  // that a lazy product left the dtype's range (exec_scales_suspect); it then stays eager.
+  bool eager_rescale = false;
+  bool eager_forced = false;        // ctn_exec_set_rescale_mode(1)
+  int eager_reruns = 0;
+  std::vector<double> h_resc;       // host copy of the last run's per-step rescale factors [R][n_steps]
   int timing_slots = 0;             // 0 = timing off
   int timing_runs = 0;              // enqueues recorded since timing was enabled
   std::vector<hipEvent_t> events;   // [slot][step][2]
 
   ~Exec() {
-    (void)hipSetDevice(device);
+    DeviceGuard dg(device);
     for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch, (void*)d_slab, (void*)d_slab2,
                     (void*)d_log, (void*)d_resc, (void*)d_logs, (void*)d_chain, d_ones, (void*)d_stepP, (void*)d_stepNumel,
                     (void*)d_stage_in, (void*)d_stage_out})
@@ -274,7 +296,7 @@ static int exec_launch_steps(Exec* E) {
     a.ptrs = E->d_ptrs;
     auto part_of = [&](int id, const double** p, int32_t* cnt, double* numel) {
       *p = nullptr; *cnt = 0; *numel = 1;
-      if (id >= P.n_inputs && P.stabilize) {
+      if (id >= P.n_inputs && P.stabilize && !E->eager_rescale) {
         const int ps = P.tensors[id].producer;
         *p = E->d_partials + (size_t)ps * R * kMaxPartials;
         *cnt = E->step_partials[ps];
@@ -550,6 +572,17 @@ static int exec_launch_steps(Exec* E) {
     }
     if (st.collapse && !reduced)
       hipLaunchKernelGGL(k_collapse, dim3(R), dim3(256), 0, E->stream, (const double*)E->d_scratch, collapse_blocks, part_dst);
+    if (E->eager_rescale && P.stabilize && s + 1 < P.n_steps) {   // the final tensor is normalised by k_finalize
+      const int64_t numel = P.tensors[st.out].numel;
+      const int V = P.dtype == CTN_F64 ? 2 : 4;
+      const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / V + 255) / 256, 2048)), R);
+      if (P.dtype == CTN_F32)
+        hipLaunchKernelGGL(k_renorm<float>, g, dim3(256), 0, E->stream, (void* const*)E->d_ptrs, E->n_tensors, st.out, numel,
+                           (const double*)part_dst, E->step_partials[s], P.min_norm);
+      else
+        hipLaunchKernelGGL(k_renorm<double>, g, dim3(256), 0, E->stream, (void* const*)E->d_ptrs, E->n_tensors, st.out, numel,
+                           (const double*)part_dst, E->step_partials[s], P.min_norm);
+    }
     if (timed) HIPCHECK(hipEventRecord(E->events[ev0 + 1], E->stream));
   }
   FinalArgs f;
@@ -588,7 +621,7 @@ static int exec_launch_all(Exec* E) {
   const Plan& P = *E->plan;
   const bool timed = E->timing_runs < E->timing_slots;
   const bool chain = P.chain && E->d_chain != nullptr;
-  if (!E->use_graph || timed || chain || P.n_steps < 4 || getenv("CTN_DEBUG_STAMPS")) return exec_launch_steps(E);
+  if (!E->use_graph || timed || chain || P.n_steps < 4 || E->eager_rescale || getenv("CTN_DEBUG_STAMPS")) return exec_launch_steps(E);
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(E->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
     (void)hipGetLastError();
@@ -752,7 +785,8 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   int rc = ctn_device_count(&ndev);
   if (rc != CTN_OK) return rc;
   if (device < 0 || device >= ndev) { g_err = "device index out of range"; return CTN_INVALID_ARG; }
-  HIPCHECK(hipSetDevice(device));
+  DeviceGuard dg(device);
+  HIPCHECK(dg.err);
   int n_cu = 256;
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
   ctn_exec* x = new (std::nothrow) ctn_exec();
@@ -863,7 +897,8 @@ void ctn_exec_destroy(ctn_exec* exec) { delete exec; }
 int ctn_exec_enqueue(ctn_exec* exec, const void* const* dev_inputs, void* const* dev_outs) {
   if (!exec || !dev_inputs || !dev_outs) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
   Exec* E = &exec->e;
-  HIPCHECK(hipSetDevice(E->device));
+  DeviceGuard dg(E->device);
+  HIPCHECK(dg.err);
   int rc = exec_set_pointers(E, dev_inputs, dev_outs);
   if (rc != CTN_OK) return rc;
   return exec_launch_all(E);
@@ -883,25 +918,88 @@ int ctn_exec_synchronize(ctn_exec* exec) {
   return CTN_OK;
 }
 
+// Did a lazy epilogue rescale leave the dtype's range in the run whose scale registers are in E->h_resc?
+// A tile kernel accumulates on the STORED operands, A_hat sA and B_hat sB, and multiplies by 1 / (sA sB)
+// afterwards, where the reference normalises each intermediate before the next product (einsum.py:387): the
+// accumulators therefore carry about s_out sA sB, which can overflow (or sink into the subnormals) although
+// every normalised quantity is fine - operands of magnitude ~1e13 do it in fp32.  All three factors are in the
+// scale registers the run has just produced, so the test costs nothing on the device: non-finite anywhere, an
+// accumulator magnitude beyond 2^+-100 (fp32; 2^+-900 fp64), or an all-zero output behind operand scales that
+// could have flushed it.
+static bool exec_scales_suspect(const Exec* E) {
+  const Plan& P = *E->plan;
+  if (!P.stabilize || (P.chain && E->d_chain)) return false;   // the chain walker divides operands on load
+  const double hi = std::ldexp(1.0, P.dtype == CTN_F64 ? 900 : 100), lo = 1.0 / hi;
+  const double zhi = std::ldexp(1.0, P.dtype == CTN_F64 ? 500 : 60), zlo = 1.0 / zhi;
+  for (int r = 0; r < E->R; ++r) {
+    const double* rs = E->h_resc.data() + (size_t)r * P.n_steps;
+    for (int s = 0; s < P.n_steps; ++s) {
+      const Step& st = P.steps[s];
+      auto scale_of = [&](int id) {
+        if (id < P.n_inputs) return 1.0;
+        const double v = rs[P.tensors[id].producer];
+        return v == 0.0 ? 1.0 : v;
+      };
+      const double sab = scale_of(st.lhs) * (st.rhs >= 0 ? scale_of(st.rhs) : 1.0);
+      const double so = rs[s];
+      if (!std::isfinite(so) || !std::isfinite(sab)) return true;
+      if (so == 0.0) { if (sab > zhi || sab < zlo) return true; continue; }
+      const double acc = so * sab;
+      if (!(acc < hi) || !(acc > lo)) return true;
+    }
+  }
+  return false;
+}
+
+// Wait for the stream, read the scale registers, and - in the default lazy mode - repeat the contraction in
+// eager mode when they show that a lazy product left the dtype's range.  The operands are still in place: they
+// are borrowed until the fetch.
+static int exec_fetch_checked(Exec* E, double* log_scale) {
+  const Plan& P = *E->plan;
+  E->h_resc.resize((size_t)E->R * P.n_steps);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (log_scale)
+      HIPCHECK(hipMemcpyAsync(log_scale, E->d_log, (size_t)E->R * 8, hipMemcpyDeviceToHost, E->stream));
+    HIPCHECK(hipMemcpyAsync(E->h_resc.data(), E->d_resc, E->h_resc.size() * 8, hipMemcpyDeviceToHost, E->stream));
+    HIPCHECK(hipStreamSynchronize(E->stream));
+    if (E->eager_rescale || !E->ptrs_valid || !exec_scales_suspect(E)) break;
+    E->eager_rescale = true;
+    E->eager_reruns++;
+    const int rc = exec_launch_all(E);
+    if (rc != CTN_OK) return rc;
+  }
+  return CTN_OK;
+}
+
 int ctn_exec_fetch(ctn_exec* exec, double* log_scale, double* step_rescales) {
   if (!exec) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
   Exec* E = &exec->e;
-  HIPCHECK(hipSetDevice(E->device));
-  if (log_scale)
-    HIPCHECK(hipMemcpyAsync(log_scale, E->d_log, (size_t)E->R * 8, hipMemcpyDeviceToHost, E->stream));
-  if (step_rescales)
-    HIPCHECK(hipMemcpyAsync(step_rescales, E->d_resc, (size_t)E->R * E->plan->n_steps * 8,
-                            hipMemcpyDeviceToHost, E->stream));
-  HIPCHECK(hipStreamSynchronize(E->stream));
+  DeviceGuard dg(E->device);
+  HIPCHECK(dg.err);
+  const int rc = exec_fetch_checked(E, log_scale);
+  if (rc != CTN_OK) return rc;
+  if (step_rescales) memcpy(step_rescales, E->h_resc.data(), E->h_resc.size() * 8);
   return CTN_OK;
 }
+
+int ctn_exec_set_rescale_mode(ctn_exec* exec, int mode) {
+  if (!exec || mode < 0 || mode > 1) { g_err = "rescale mode must be 0 (lazy, eager on demand) or 1 (eager)"; return CTN_INVALID_ARG; }
+  Exec* E = &exec->e;
+  const int prev = E->eager_rescale ? 1 : 0;
+  E->eager_forced = mode == 1;
+  E->eager_rescale = mode == 1;
+  return prev;
+}
+
+int ctn_exec_eager_reruns(const ctn_exec* exec) { return exec ? exec->e.eager_reruns : CTN_INVALID_ARG; }
 
 int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space, void* const* outs,
                  int outs_space, double* log_scale, double* step_rescales) {
   if (!exec || !inputs || !outs) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
   Exec* E = &exec->e;
   const Plan& P = *E->plan;
-  HIPCHECK(hipSetDevice(E->device));
+  DeviceGuard dg(E->device);
+  HIPCHECK(dg.err);
   const size_t es = P.elem_size();
   const int64_t out_bytes = P.output().numel * (int64_t)es;
   const int64_t out_slot = (out_bytes + kAlign - 1) / kAlign * kAlign;
@@ -950,18 +1048,24 @@ int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space, vo
   if (rc != CTN_OK) return rc;
   rc = exec_launch_all(E);
   if (rc != CTN_OK) return rc;
-  if (outs_space == CTN_MEM_HOST)
+  rc = exec_fetch_checked(E, log_scale);      // may repeat the contraction in eager-rescale mode
+  if (rc != CTN_OK) return rc;
+  if (step_rescales) memcpy(step_rescales, E->h_resc.data(), E->h_resc.size() * 8);
+  if (outs_space == CTN_MEM_HOST) {
     for (int r = 0; r < E->R; ++r) {
       if (!outs[r]) { g_err = "null output pointer"; return CTN_INVALID_ARG; }
       HIPCHECK(hipMemcpyAsync(outs[r], dout[r], (size_t)out_bytes, hipMemcpyDeviceToHost, E->stream));
     }
-  return ctn_exec_fetch(exec, log_scale, step_rescales);
+    HIPCHECK(hipStreamSynchronize(E->stream));
+  }
+  return CTN_OK;
 }
 
 int ctn_exec_set_timing(ctn_exec* exec, int slots) {
   if (!exec || slots < 0) { g_err = "invalid argument"; return CTN_INVALID_ARG; }
   Exec* E = &exec->e;
-  HIPCHECK(hipSetDevice(E->device));
+  DeviceGuard dg(E->device);
+  HIPCHECK(dg.err);
   HIPCHECK(hipStreamSynchronize(E->stream));
   const size_t need = (size_t)slots * E->plan->n_steps * 2;
   while (E->events.size() < need) {

@@ -383,6 +383,34 @@ __global__ __launch_bounds__(256) void k_finalize(FinalArgs f, const double* __r
 }
 
 // ---------------------------------------------------------------------------
+// k_renorm: the reference's stabilize() applied to a stored intermediate, literally (einsum.py:97-106:
+// T <- T / rescale when sum|T| > min_norm).  Only the EAGER rescale mode launches it (engine.hip): there every
+// intermediate is normalised in place right after its step and consumers take it with scale 1, so no product
+// ever sees an un-normalised operand - what the lazy epilogue rescale of the tile kernels cannot promise when
+// operand magnitudes are extreme (sA * sB * sum beyond the dtype's range).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_renorm(void* const* __restrict__ ptrs, int n_tensors, int id, int64_t numel,
+                                                const double* __restrict__ part, int P, double min_norm) {
+  const int r = blockIdx.y;
+  bool cond = false;
+  const T sc = producer_scale<T>(part, P, (double)numel, min_norm, r, &cond);
+  if (!cond) return;
+  T* __restrict__ x = (T*)ptrs[(size_t)r * n_tensors + id];
+  constexpr int V = 16 / sizeof(T);
+  typedef typename VecOf<T, V>::type VT;
+  const int64_t nv = numel / V;            // workspace tensors start on 256-byte boundaries
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    VT v = reinterpret_cast<VT*>(x)[i];
+    T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int j = 0; j < V; ++j) e[j] = e[j] / sc;
+    reinterpret_cast<VT*>(x)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(numel - nv * V)) x[nv * V + threadIdx.x] = x[nv * V + threadIdx.x] / sc;
+}
+
+// ---------------------------------------------------------------------------
 // K-chain: persistent small-tensor DAG walker.  One workgroup per replica executes EVERY step of
 // the plan in order (reference loop einsum.py:341-391) - no per-step launch, rescale factors of
 // all produced tensors kept in LDS.  Same arithmetic as k_element (operands divided by their

@@ -88,6 +88,45 @@ def choose_slices_with_path(einstr, shapes, min_slices=1, max_intermediate=None,
     return tuple(chosen), tuple(tuple(p) for p in path), report
 
 
+def sliced_plan(einstr, shapes, min_slices=1, max_intermediate=None, cache_dir=None, **kwargs):
+    """`choose_slices_with_path` behind a file cache: the search takes tens of seconds on the host and depends
+    only on the network's structure, so its result ``(labels, path, report)`` is kept as JSON under
+    ``cache_dir`` (default ``contractn_amd/plans/``), keyed by a hash of (einsum string, shapes, targets).
+    A cached entry is checked against the network before use (labels contracted, path reduces the operands)."""
+    import hashlib
+    import json
+    import os
+
+    shapes = [tuple(int(d) for d in s) for s in shapes]
+    cache_dir = cache_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans")
+    key = hashlib.sha1(json.dumps([einstr, shapes, int(min_slices), max_intermediate, sorted(kwargs.items())],
+                                  ensure_ascii=True).encode()).hexdigest()[:16]
+    fname = os.path.join(cache_dir, f"sliced_{key}.json")
+    if os.path.exists(fname):
+        try:
+            with open(fname) as fh:
+                d = json.load(fh)
+            labels = tuple(d["labels"])
+            path = tuple(tuple(int(x) for x in p) for p in d["path"])
+            lhs, out = einstr.split("->")
+            if (d.get("einsum_str") == einstr and all(lab in lhs and lab not in out for lab in labels)
+                    and len(path) == len(shapes) - 1):
+                return labels, path, d["report"]
+        except (OSError, ValueError, KeyError):
+            pass
+    labels, path, report = choose_slices_with_path(einstr, shapes, min_slices=min_slices,
+                                                   max_intermediate=max_intermediate, **kwargs)
+    try:
+        os.makedirs(cache_dir, exist_ok=True)
+        with open(fname, "w") as fh:
+            json.dump({"einsum_str": einstr, "shapes": shapes, "min_slices": int(min_slices),
+                       "max_intermediate": max_intermediate, "labels": list(labels),
+                       "path": [list(p) for p in path], "report": report}, fh)
+    except OSError:
+        pass   # read-only installation: search again next time
+    return labels, path, report
+
+
 def shard_range(n_items, rank, world):
     """Contiguous, balanced share of ``range(n_items)`` for ``rank``."""
     base, extra = divmod(n_items, world)
@@ -244,14 +283,20 @@ def contract_sliced(einstr, operands, slice_labels, optimize="auto", contract_fn
     return all_gather_combine(t_loc, c_loc, group=group, world=world)
 
 
-def all_gather_combine(t_loc, c_loc, group=None, world=None):
-    """THE join: one all_gather of the packed ``(T_hat, c)`` buffers, then a local combine."""
+def all_gather_combine(t_loc, c_loc, group=None, world=None, device=None):
+    """THE join: one all_gather of the packed ``(T_hat, c)`` buffers, then a local combine.
+
+    ``device``: the GPU this rank computes on (RCCL needs the buffers there); defaults to torch's current
+    device.  With the gloo backend (CPU tests, one-GPU rehearsals) the buffers stay on the host."""
     import torch
     import torch.distributed as dist
 
     world = world or dist.get_world_size(group)
     backend = dist.get_backend(group)
-    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    if backend == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    else:
+        device = torch.device("cpu")
     flat = np.concatenate([np.asarray(t_loc, dtype=np.float64).ravel(), [float(c_loc)]])
     send = torch.from_numpy(flat).to(device)
     recv = [torch.empty_like(send) for _ in range(world)]
@@ -357,6 +402,10 @@ class SlicedContraction:
                             for r in range(R)]
                 self._chunks.append((c0, n, self.bc.executor.make_enqueue(in_ptrs, out_ptrs)))
             self.R = R
+            # everything above was prepared on torch's current stream (uploads, clones of odd-sized slices, the
+            # zero fills); the executor runs on its own non-blocking stream, which does not order against it
+            torch.cuda.current_stream(dev).synchronize()
+        self.last_slices = None   # (T_hat [n_local, ...], log_scale [n_local]) of the last local_result()
 
     def local_result(self):
         """Run this rank's slices group by group and combine them (split format); an exact zero
@@ -368,6 +417,7 @@ class SlicedContraction:
             launch()
             logs[c0:c0 + n] = self.bc.fetch_log_scale()[:n]   # waits for the group
         t = self.out.cpu().numpy()
+        self.last_slices = (t, logs)
         return combine_split([(t[r], logs[r]) for r in range(len(self.my_slices))])
 
     def run(self, group=None):
@@ -375,4 +425,4 @@ class SlicedContraction:
         t_loc, c_loc = self.local_result()
         if self.world == 1:
             return t_loc, c_loc
-        return all_gather_combine(t_loc, c_loc, group=group, world=self.world)
+        return all_gather_combine(t_loc, c_loc, group=group, world=self.world, device=self.device)

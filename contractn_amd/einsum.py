@@ -17,6 +17,7 @@ error behaviour:
 
 There is no CPU fallback: without the HIP library or a GPU, ``contract`` raises.
 """
+import threading
 from collections import OrderedDict
 from functools import lru_cache
 
@@ -124,7 +125,7 @@ def lower_contraction_list(n_operands, contract_list):
 
 
 @lru_cache(maxsize=256)
-def _native_plan(contract_list, shapes, dtype_name):
+def _native_plan_cached(contract_list, shapes, dtype_name):
     in_labels, steps = lower_contraction_list(len(shapes), contract_list)
     for lab, shp in zip(in_labels, shapes):
         if len(lab) != len(shp):
@@ -132,31 +133,58 @@ def _native_plan(contract_list, shapes, dtype_name):
     return engine.Plan(dtype_name, in_labels, shapes, steps, stabilize=True, min_norm=MIN_NORM)
 
 
+_PLAN_LOCK = threading.Lock()
+
+
+def _native_plan(contract_list, shapes, dtype_name):
+    """Cached native plan.  (``lru_cache`` does not serialise misses: without the lock two threads asking for
+    the same new plan would each build one, and executors are keyed by plan identity.)"""
+    with _PLAN_LOCK:
+        return _native_plan_cached(contract_list, shapes, dtype_name)
+
+
+_native_plan.cache_clear = _native_plan_cached.cache_clear
+_native_plan.cache_info = _native_plan_cached.cache_info
+
+
 # Executors own device memory (workspace, tables, staging).  They are kept in a small LRU so that a
 # process contracting many differently-shaped networks does not accumulate workspaces without bound;
 # an evicted executor frees its device memory immediately (the plan itself is host-only and cheap).
+#
+# Threads: the reference's ``contract`` is re-entrant, a native executor is not (one workspace, one pointer
+# table, one graph capture).  Executors are therefore cached PER THREAD - the key carries the caller's thread
+# id - so two threads contracting the same network run on two executors concurrently instead of queueing on
+# one; in addition every use holds the executor's own lock from launch to fetch (an evicting thread waits in
+# ``close`` for a run in flight).
 _EXECUTOR_LRU = OrderedDict()
+_EXECUTOR_LRU_LOCK = threading.Lock()
 MAX_CACHED_EXECUTORS = 16
 
 
 def _executor_for(plan, replicas=1, device=0, stream=None):
-    key = (id(plan), replicas, device, stream)
-    ex = _EXECUTOR_LRU.get(key)
-    if ex is not None:
-        _EXECUTOR_LRU.move_to_end(key)
-        return ex
+    key = (id(plan), replicas, device, stream, threading.get_ident())
+    evicted = []
+    with _EXECUTOR_LRU_LOCK:
+        ex = _EXECUTOR_LRU.get(key)
+        if ex is not None:
+            _EXECUTOR_LRU.move_to_end(key)
+            return ex
     ex = engine.Executor(plan, replicas=replicas, device=device, stream=stream)
-    _EXECUTOR_LRU[key] = ex
-    while len(_EXECUTOR_LRU) > MAX_CACHED_EXECUTORS:
-        _, old = _EXECUTOR_LRU.popitem(last=False)
+    with _EXECUTOR_LRU_LOCK:
+        _EXECUTOR_LRU[key] = ex
+        while len(_EXECUTOR_LRU) > MAX_CACHED_EXECUTORS:
+            evicted.append(_EXECUTOR_LRU.popitem(last=False)[1])
+    for old in evicted:   # outside the table lock: close() waits for a run that is still in flight
         old.close()
     return ex
 
 
 def clear_caches():
     """Drop every cached executor (device memory), native plan and contraction path."""
-    while _EXECUTOR_LRU:
-        _, ex = _EXECUTOR_LRU.popitem()
+    with _EXECUTOR_LRU_LOCK:
+        dropped = list(_EXECUTOR_LRU.values())
+        _EXECUTOR_LRU.clear()
+    for ex in dropped:
         ex.close()
     _native_plan.cache_clear()
     _contract_path.cache_clear()
@@ -253,7 +281,8 @@ def _core_contract(operands, contract_list, backend="numpy", **einsum_kwargs):
     if backend == "torch":
         return _run_torch(plan, operands, dtype)
     ex = _executor_for(plan, 1)
-    outs, _dev_log, resc = ex.run_host([operands])
+    with ex.lock:
+        outs, _dev_log, resc = ex.run_host([operands])
     log_scale = accumulate_log_scale(resc[0], dtype)
     return outs[0], log_scale
 
@@ -262,10 +291,17 @@ def _run_torch(plan, operands, dtype):
     import torch
 
     tdt = torch.float32 if dtype == np.float32 else torch.float64
+    if torch.is_grad_enabled() and any(o.requires_grad for o in operands):
+        # the reference's torch backend is differentiable (einsum.py:9-21); this engine writes into a fresh
+        # buffer outside autograd, so a training loop would silently get no gradients - refuse instead
+        raise NotImplementedError(
+            "the HIP engine does not build an autograd graph: detach() the operands or contract under "
+            "torch.no_grad()")
     if not all(o.is_cuda for o in operands):
         ex = _executor_for(plan, 1)
         host = [o.detach().cpu().numpy() for o in operands]
-        outs, _dev_log, resc = ex.run_host([host])
+        with ex.lock:
+            outs, _dev_log, resc = ex.run_host([host])
         log_scale = accumulate_log_scale(resc[0], dtype)
         return torch.from_numpy(outs[0]), torch.tensor(float(log_scale), dtype=tdt)
     dev = operands[0].device
@@ -280,8 +316,9 @@ def _run_torch(plan, operands, dtype):
         # it runs on its own non-blocking stream, so wait for the producers of the operands first
         tstream.synchronize()
     ex = _executor_for(plan, 1, device=dev.index or 0, stream=stream)
-    ex.enqueue([o.data_ptr() for o in ops], [out.data_ptr()])
-    _dev_log, resc = ex.fetch()
+    with ex.lock:
+        ex.enqueue([o.data_ptr() for o in ops], [out.data_ptr()])
+        _dev_log, resc = ex.fetch()
     log_scale = accumulate_log_scale(resc[0], dtype)
     return out, torch.tensor(float(log_scale), dtype=tdt, device=dev)
 

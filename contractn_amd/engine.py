@@ -6,6 +6,7 @@ pure host objects, so they can be built and inspected without a GPU.
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -36,7 +37,7 @@ ABI_SYMBOLS = (
     "ctn_plan_workspace_bytes", "ctn_plan_step_info",
     "ctn_exec_create", "ctn_exec_destroy", "ctn_exec_run", "ctn_exec_enqueue",
     "ctn_exec_fetch", "ctn_exec_synchronize", "ctn_exec_set_timing", "ctn_exec_step_ms",
-    "ctn_exec_step_tile",
+    "ctn_exec_step_tile", "ctn_exec_set_rescale_mode", "ctn_exec_eager_reruns",
 )
 
 
@@ -148,6 +149,8 @@ def load_library():
         "ctn_exec_set_timing": (i32, [vp, i32]),
         "ctn_exec_step_ms": (i32, [vp, C.POINTER(C.c_float)]),
         "ctn_exec_step_tile": (i32, [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        "ctn_exec_set_rescale_mode": (i32, [vp, i32]),
+        "ctn_exec_eager_reruns": (i32, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -268,6 +271,10 @@ class Executor:
         _check(lib.ctn_exec_create(plan._h, self.device, C.c_void_p(stream or 0), self.replicas,
                                    C.byref(handle)))
         self._h = handle
+        # A native executor owns mutable device state (pointer table, workspace, staging, graph capture) and
+        # ctypes releases the GIL inside the native calls: whoever drives it holds this lock from
+        # run_host / enqueue through fetch (include/ctn_abi.h, "Threading")
+        self.lock = threading.RLock()
         self._log = np.zeros(self.replicas, dtype=np.float64)
         self._resc = np.zeros((self.replicas, plan.n_steps), dtype=np.float64)
 
@@ -279,6 +286,11 @@ class Executor:
         """
         plan, R = self.plan, self.replicas
         assert len(operand_sets) == R
+        with self.lock:
+            return self._run_host_locked(operand_sets)
+
+    def _run_host_locked(self, operand_sets):
+        plan, R = self.plan, self.replicas
         keep = []
         ptrs = (C.c_void_p * (R * plan.n_inputs))()
         for r, ops in enumerate(operand_sets):
@@ -329,6 +341,15 @@ class Executor:
     def synchronize(self):
         _check(self._lib.ctn_exec_synchronize(self._h))
 
+    def set_rescale_mode(self, mode):
+        """0 = lazy rescale with overflow detection (default), 1 = eager (the reference's order); returns the
+        previous mode."""
+        return _check(self._lib.ctn_exec_set_rescale_mode(self._h, int(mode)))
+
+    def eager_reruns(self):
+        """How often a fetch found a lazily rescaled product out of range and repeated the contraction eagerly."""
+        return _check(self._lib.ctn_exec_eager_reruns(self._h))
+
     def set_timing(self, slots):
         """Bracket every step of the next ``slots`` enqueues with HIP events (0 = off)."""
         _check(self._lib.ctn_exec_set_timing(self._h, int(slots)))
@@ -348,9 +369,13 @@ class Executor:
         return ms
 
     def close(self):
-        h, self._h = getattr(self, "_h", None), None
-        if h:
-            self._lib.ctn_exec_destroy(h)
+        lock = getattr(self, "lock", None)
+        if lock is None:      # __init__ failed before the handle existed
+            return
+        with lock:            # never under a thread that is still inside run_host / enqueue .. fetch
+            h, self._h = getattr(self, "_h", None), None
+            if h:
+                self._lib.ctn_exec_destroy(h)
 
     def __del__(self):
         self.close()

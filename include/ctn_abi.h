@@ -149,9 +149,26 @@ int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space,
 
 /* Asynchronous variant: device pointers only, returns after enqueueing on the stream. */
 int ctn_exec_enqueue(ctn_exec* exec, const void* const* dev_inputs, void* const* dev_outs);
-/* Wait for the stream and copy out the scale registers of the last enqueue (either may be NULL). */
+/* Wait for the stream and copy out the scale registers of the last enqueue (either may be NULL).
+ * The operands and outputs of that enqueue stay borrowed until this call returns: when the scale registers
+ * show that a lazily rescaled product left the dtype's range (see ctn_exec_set_rescale_mode) the contraction is
+ * repeated here, into the same output buffers, before anything is reported. */
 int ctn_exec_fetch(ctn_exec* exec, double* log_scale, double* step_rescales);
 int ctn_exec_synchronize(ctn_exec* exec);
+
+/*
+ * Where stabilize() (reference einsum.py:89-107, called at :387 after every step) is applied.
+ *   0  lazy, the default: a step stores its un-normalised output and consumers fold 1 / (sA sB) into their
+ *      epilogue - no extra pass over HBM.  The tile kernels then accumulate on un-normalised operands, which
+ *      can leave the dtype's range where the reference stays finite (fp32 operands of magnitude ~1e13); every
+ *      fetch checks the scale registers for that and, if so, switches the executor to mode 1 and repeats the
+ *      contraction (ctn_exec_eager_reruns counts how often).
+ *   1  eager: every intermediate is divided by its rescale in place right after its step and consumed with
+ *      scale 1 - the reference's own order of operations, one extra read+write per intermediate.
+ * Returns the previous mode, or a negative ctn_status.
+ */
+int ctn_exec_set_rescale_mode(ctn_exec* exec, int mode);
+int ctn_exec_eager_reruns(const ctn_exec* exec);
 
 /*
  * Workgroup tile (rows, columns) of the MFMA kernel that the LAST enqueue launched for `step`

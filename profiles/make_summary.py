@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Turn raw rocprofv3 outputs (gpurun_out/, scratch) into the committed per-round summaries.
 
-    python profiles/make_summary.py r01 gpurun_out/prof_r01 gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq
+    python profiles/make_summary.py r02 gpurun_out/prof_r02 gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq \
+        gpurun_out/bench_default.json
+
+The last argument is the bench line of the same command in the same gpurun call: its workload name and dominant-kernel
+label are stored next to the counters, and bench.py attaches `roofline.traffic` only to a run that matches both.
 
 Writes profiles/<round>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, ctn kernels only),
 profiles/<round>_pmc_summary.json (per-kernel counter means) and profiles/pmc_traffic.json
@@ -31,6 +35,16 @@ def counters(path):
 
 def main():
     tag, stats_dir, fetch_dir, write_dir, sq_dir = sys.argv[1:6]
+    bench = {}
+    if len(sys.argv) > 6:
+        bench = json.loads(open(sys.argv[6]).read().strip().splitlines()[-1])
+    import subprocess
+
+    try:
+        sha = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                             cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or "unknown"
+    except OSError:
+        sha = "unknown"
     here = os.path.dirname(os.path.abspath(__file__))
     rows = list(csv.reader(open(find(stats_dir, "kernel_stats.csv"))))
     with open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
@@ -53,7 +67,10 @@ def main():
     json.dump(summary, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     stat_rows = {r[0]: float(r[2]) for r in rows[1:] if "ctn::" in r[0]}
     dom = max(stat_rows, key=stat_rows.get)
-    traffic = {"kernel": dom, "round": tag,
+    traffic = {"kernel": dom, "round": tag, "git_sha": sha,
+               "workload": bench.get("config", {}).get("workload"),
+               "kernel_label": bench.get("roofline", {}).get("kernel"),
+               "algorithmic_bytes_per_launch": bench.get("roofline", {}).get("algorithmic_bytes_per_launch"),
                "hbm_bytes_per_launch": summary.get(dom, {}).get("hbm_bytes_per_launch"),
                "note": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, mean over launches"}
     json.dump(traffic, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)

@@ -133,3 +133,34 @@ def test_choose_slices_with_path_co_optimises_and_reproduces_the_value():
         e, *o, path=list(path), split_format=kw.get("split_format", True)))
     t_u, c_u = oracle_contract(tn.einsum_str, *ops)
     np.testing.assert_allclose(np.asarray(t_s) * np.exp(float(c_s)), np.asarray(t_u) * np.exp(float(c_u)), rtol=1e-9)
+
+
+def test_sliced_plan_is_cached_on_disk_and_validated(tmp_path):
+    """`dist.sliced_plan`: the tens-of-seconds search runs once per network; the cached entry is re-used only
+    for the same network and only when it is still a valid (labels, path) pair for it."""
+    import json
+    import time
+
+    from contractn_amd import TN, dist
+    from tests import networks as nets
+
+    tn = nets.peps_closed(TN, 3, 3, 3, dtype=np.float64, seed=6)
+    shapes = [o.shape for o in tn.params]
+    first = dist.sliced_plan(tn.einsum_str, shapes, min_slices=9, cache_dir=str(tmp_path), trials=1)
+    files = list(tmp_path.glob("sliced_*.json"))
+    assert len(files) == 1 and first[2]["slices"] >= 9
+    t0 = time.perf_counter()
+    again = dist.sliced_plan(tn.einsum_str, shapes, min_slices=9, cache_dir=str(tmp_path), trials=1)
+    assert time.perf_counter() - t0 < 0.05 and again[:2] == first[:2]
+    # a corrupted entry (labels that are not in the network) is ignored and searched again
+    d = json.load(open(files[0]))
+    d["labels"] = ["☃"]
+    json.dump(d, open(files[0], "w"))
+    third = dist.sliced_plan(tn.einsum_str, shapes, min_slices=9, cache_dir=str(tmp_path), trials=1)
+    assert third[:2] == first[:2]
+    # the labels/path it returns contract to the unsliced value
+    ops = list(tn.params)
+    t_s, c_s = dist.contract_sliced(tn.einsum_str, ops, first[0], contract_fn=lambda e, *o, **kw: cpu_ref.contract(
+        e, *o, path=list(first[1]), split_format=True))
+    t_u, c_u = oracle_contract(tn.einsum_str, *ops)
+    np.testing.assert_allclose(np.asarray(t_s) * np.exp(float(c_s)), np.asarray(t_u) * np.exp(float(c_u)), rtol=1e-10)

@@ -1,0 +1,110 @@
+"""World-size-2 runs whose compute is the HIP engine.
+
+A GPU box of this pool has ONE card, so the two ranks are two fresh child processes that both compute on
+``cuda:0`` and join over ``gloo`` (the rehearsal knobs ``CTN_BENCH_BACKEND=gloo CTN_BENCH_ONE_DEVICE=1`` of
+bench.py); on a multi-GPU node the same code runs one rank per card over RCCL.  What is under test is the
+product path end to end: slices dealt to the ranks, every rank running ITS slices as replicas of one plan on the
+engine, ONE all_gather of ``(T_hat, c)`` and the log-sum-exp combine - against the unsliced engine result and
+the CPU oracle."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, rows, cols, bond, labels, path, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as tdist
+
+    from contractn_amd import TN, dist, engine
+    from tests import networks as nets
+
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert engine.device_count() >= 1
+        tn = nets.peps_closed(TN, rows, cols, bond, dtype=np.float32, seed=6)
+        sc = dist.SlicedContraction(tn.einsum_str, list(tn.params), labels, optimize=path, rank=rank, world=world,
+                                    device=0)
+        t, c = sc.run()                       # HIP engine on this rank's slices + the all_gather join
+        q.put((rank, len(sc.my_slices), sc.n_total, float(t), float(c)))
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_two_ranks_hip_engine_and_all_gather_join():
+    import torch.multiprocessing as mp
+
+    from contractn_amd import TN, dist
+    from contractn_amd.paths import ssa_to_linear
+    from oracle import cpu_ref
+    from tests import networks as nets
+
+    rows = cols = 5
+    bond = 4
+    tn = nets.peps_closed(TN, rows, cols, bond, dtype=np.float32, seed=6)
+    ops = list(tn.params)
+    labels, path, rep = dist.choose_slices_with_path(tn.einsum_str, [o.shape for o in ops], min_slices=16, trials=1)
+    assert rep["slices"] >= 16
+    # references: the CPU oracle and the engine, both unsliced, on the row sweep
+    row = ssa_to_linear(nets.peps_row_path(rows, cols), 2 * rows * cols)
+    rt, rc = cpu_ref.contract(tn.einsum_str, *ops, path=row, split_format=True)
+    et, ec = tn.contract(optimize=row, split_format=True)
+    assert float(et) == float(rt) and abs(float(ec) - float(rc)) <= 1e-4
+
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, rows, cols, bond, labels, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, n0, tot0, t0, c0), (r1, n1, tot1, t1, c1) = results
+    assert (r0, r1) == (0, 1) and tot0 == tot1 == rep["slices"] and n0 + n1 == tot0 and abs(n0 - n1) <= 1
+    assert (t0, c0) == (t1, c1)                                  # every rank holds the same joined result
+    assert t0 == float(rt) and abs(c0 - float(rc)) <= 1e-3       # north_star tolerance, fp32
+
+
+def test_bench_peps_two_ranks_rehearsal():
+    """`bench.py --config peps --gpus 2` under torch.distributed.run (both ranks on cuda:0, gloo): the JSON line
+    carries the strong-scaling contract, the roofline of the dominant kernel and a finite, correct value."""
+    env = dict(os.environ, CTN_BENCH_BACKEND="gloo", CTN_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--config", "peps", "--rows", "4", "--cols", "4", "--bond", "4", "--slices", "8", "--steps", "3",
+              "--warmup", "2", "--cpu-seconds", "2"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    line1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert line1["n_gpus"] == 1 and line1["scaling"] == "strong" and line1["config"]["slices"] >= 8
+    assert line1["cpu_baseline"]["parity_vs_gpu"]["ok"], line1["cpu_baseline"]
+    assert line1["unsliced_check"]["ok"], line1["unsliced_check"]
+    assert line1["roofline"]["bound"] in ("mfma", "hbm") and line1["roofline"]["achieved"] > 0
+
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    line2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and line2["config"]["slices_per_gpu"] * 2 == line2["config"]["slices"]
+    # the same network, the same slices: the joined value does not depend on how many ranks shared the work
+    assert line2["result"]["t_hat"] == line1["result"]["t_hat"]
+    assert abs(line2["result"]["log_scale"] - line1["result"]["log_scale"]) <= 1e-5

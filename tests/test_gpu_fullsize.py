@@ -1,0 +1,137 @@
+"""The BASELINE configs at the sizes SURVEY.md 8(d) names (their feasible renditions), on the GPU.
+
+Where the CPU oracle finishes in seconds it is the checker (config 3a at the full 100 sites; config 5 at D = 2, 3);
+beyond that the checks are size-independent properties: entries against the definition evaluated in float64,
+CP through a copy node == Tucker through a materialised delta hub, and one network contracted along three different
+routes (hand-written sweep, the library's own path, index-sliced) giving one value."""
+import numpy as np
+import pytest
+
+from contractn_amd import TN, contract, dist
+from contractn_amd import einsum as E
+from contractn_amd.paths import ssa_to_linear
+from oracle import cpu_ref
+from tests import networks as nets
+
+pytestmark = pytest.mark.gpu
+
+
+def full(t, c):
+    return np.asarray(t, dtype=np.float64) * np.exp(float(c))
+
+
+# ---- config 3a: the metric's network, all 100 sites ---------------------------------------------------------------
+def test_cfg3a_full_100_sites_bond256_vs_oracle():
+    """<phi|psi> of two 100-site MPS, D = 256, d = 4, fp32, zipper path (BASELINE configs[2]; 199 steps,
+    26.3 GFLOP): sign equal, log-value within 1e-4 of the NumPy oracle on the same path (north_star: 1e-3)."""
+    tn, ssa = nets.mps_overlap(TN, 100, 256, 4, dtype=np.float32, seed=3, scale=16.0)
+    path = ssa_to_linear(ssa, 200)
+    fun = tn.make_contract_fun(optimize=path, split_format=True)
+    t, c = fun(tn.params, ())
+    rt, rc = cpu_ref.contract(tn.einsum_str, *tn.params, path=path, split_format=True)
+    assert t.dtype == np.float32 and float(t) == float(rt) and abs(float(t)) == 1.0
+    assert abs(float(c) - float(rc)) <= 1e-4
+    # the same network twice: bit-identical (fixed-order reductions, no float atomics)
+    t2, c2 = fun(tn.params, ())
+    assert float(t2) == float(t) and float(c2) == float(c)
+    # and in float64 to 1e-9 (north_star: 1e-6)
+    p64 = tuple(p.astype(np.float64) for p in tn.params)
+    t64, c64 = fun(p64, ())
+    r64t, r64c = cpu_ref.contract(tn.einsum_str, *p64, path=path, split_format=True)
+    assert float(t64) == float(r64t) and abs(float(c64) - float(r64c)) <= 1e-9
+
+
+# ---- config 4: CP through a copy node / Tucker with a dense hub, r = n = 1024 --------------------------------------
+def _mats(n_mats, r, n, seed, scale=32.0):
+    import torch
+
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    return [torch.randn((r, n), generator=gen, device="cuda", dtype=torch.float32) / scale for _ in range(n_mats)]
+
+
+def test_cfg4_cp_hyper_1024_entries_match_the_definition_and_the_delta_hub_network():
+    """4(i) CP-hyper r = n = 1024 (`ac,ad,ae->cde`, 2.2 TFLOP, 4 GiB out) against (a) 20 entries of
+    sum_a A[a,c] B[a,d] C[a,e] in float64 and (b) 4(iii): the same factor matrices around a MATERIALISED
+    1024^3 delta hub (`abc,ae,bf,cg->efg`, 6.6 TFLOP) - the hyperedge and the dense-hub route must agree everywhere."""
+    import torch
+
+    r = n = 1024
+    A, B, C = _mats(3, r, n, seed=5)
+    t, c = contract("ac,ad,ae->cde", A, B, C, split_format=True)
+    assert t.is_cuda and tuple(t.shape) == (n, n, n)
+    scale = float(torch.exp(c.double()))
+    peak = float(t.abs().max()) * scale
+    rng = np.random.default_rng(0)
+    for c_, d_, e_ in rng.integers(0, n, size=(20, 3)):
+        ref = float((A[:, c_].double() * B[:, d_].double() * C[:, e_].double()).sum())
+        assert abs(float(t[c_, d_, e_]) * scale - ref) <= 1e-3 * peak
+    hub = torch.zeros((r, r, r), device="cuda", dtype=torch.float32)
+    idx = torch.arange(r, device="cuda")
+    hub[idx, idx, idx] = 1.0
+    td, cd = contract("abc,ae,bf,cg->efg", hub, A, B, C, split_format=True)
+    del hub
+    # both results are (T_hat, c) with mean|T_hat| = 1: compare T_hat * exp(c) without leaving fp32 range
+    ratio = float(torch.exp(cd.double() - c.double()))
+    diff = float((td * ratio - t).abs().max())
+    assert diff * scale <= 1e-3 * peak
+    del t, td
+    torch.cuda.empty_cache()
+
+
+def test_cfg4_tucker_dense_hub_1024_entries_match_the_definition():
+    """4(ii) Tucker with a dense random 1024^3 hub (6.6 TFLOP): 12 entries against the definition in float64."""
+    import torch
+
+    r = n = 1024
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+    hub = torch.randn((r, r, r), generator=gen, device="cuda", dtype=torch.float32) / 32.0
+    A, B, C = _mats(3, r, n, seed=8)
+    t, c = contract("abc,ae,bf,cg->efg", hub, A, B, C, split_format=True)
+    scale = float(torch.exp(c.double()))
+    peak = float(t.abs().max()) * scale
+    rng = np.random.default_rng(1)
+    hub64 = hub.double()
+    for e_, f_, g_ in rng.integers(0, n, size=(12, 3)):
+        # sum_abc H[a,b,c] A[a,e] B[b,f] C[c,g], contracted leg by leg in float64
+        v = torch.einsum("abc,c->ab", hub64, C[:, g_].double())
+        ref = float(A[:, e_].double() @ v @ B[:, f_].double())
+        assert abs(float(t[e_, f_, g_]) * scale - ref) <= 1e-3 * peak
+    del hub, hub64, t
+    torch.cuda.empty_cache()
+
+
+# ---- config 5: the 8 x 8 PEPS ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bond,dtype,tol", [(2, np.float64, 1e-9), (3, np.float32, 1e-4)])
+def test_cfg5_peps_8x8_small_bond_vs_oracle(bond, dtype, tol):
+    tn = nets.peps_closed(TN, 8, 8, bond, dtype=dtype, seed=6)
+    row = ssa_to_linear(nets.peps_row_path(8, 8), 128)
+    t, c = tn.contract(optimize=row, split_format=True)
+    rt, rc = cpu_ref.contract(tn.einsum_str, *tn.params, path=row, split_format=True)
+    assert float(t) == float(rt) and abs(float(c) - float(rc)) <= tol * max(1.0, abs(float(rc)))
+    ta, ca = tn.contract(optimize="auto", split_format=True)     # the library's own path: same value
+    assert float(ta) == float(rt) and abs(float(ca) - float(rc)) <= 10 * tol * max(1.0, abs(float(rc)))
+
+
+def test_cfg5_peps_8x8_bond8_three_routes_one_value():
+    """8 x 8, D = 8 (the measured size; no CPU reference at this size): the hand-written row
+    sweep (663 GFLOP), the path `optimize="auto"` finds (247 GFLOP) and the index-sliced contraction (64 slices,
+    path chosen together with the slices, run as replicas of one plan) agree to 1e-3."""
+    import bench
+
+    einstr, shapes, ops = bench.peps_network(8, 8, 8)
+    row = ssa_to_linear(nets.peps_row_path(8, 8), 128)
+    t_r, c_r = contract(einstr, *ops, optimize=row, split_format=True)
+    t_a, c_a = contract(einstr, *ops, optimize="auto", split_format=True)
+    assert float(t_a) == float(t_r) and abs(float(c_a) - float(c_r)) <= 1e-3
+    labels, path, rep = dist.sliced_plan(einstr, shapes, min_slices=64)
+    assert rep["slices"] >= 64 and rep["largest_intermediate"] < rep["unsliced_largest_intermediate"]
+    sc = dist.SlicedContraction(einstr, ops, labels, optimize=path, rank=0, world=1)
+    t_s, c_s = sc.run()
+    assert float(t_s) == float(t_r) and abs(float(c_s) - float(c_r)) <= 1e-3
+    # two emulated ranks own disjoint halves of the slices; their split-format partials combine to the same value
+    parts = [dist.SlicedContraction(einstr, ops, labels, optimize=path, rank=r, world=2).local_result() for r in range(2)]
+    t_j, c_j = dist.combine_split(parts)
+    assert float(t_j) == float(t_r) and abs(float(c_j) - float(c_r)) <= 1e-3
+    E.clear_caches()
