@@ -29,7 +29,6 @@
 #include "kernel_args.h"
 #include "kernels_mfma.h"
 #include "kernels_mfma_g.h"
-#include "kernels_mfma_g2.h"
 #include "kernels_mfma_g64.h"
 #include "kernels_stream.h"
 
@@ -39,6 +38,33 @@ namespace ctn {
 // executor
 // ---------------------------------------------------------------------------
 thread_local std::string g_err;
+
+// Development switches: every environment variable the library looks at, read in ONE place, once per executor
+// (ctn_exec_create) - never on the launch path.  None is needed in production ("Development switches").
+struct DevSwitches {
+  int mfma_g = 1;        // CTN_MFMA_G: 0 never use the large-tile LDS-DMA kernels, 1 when a launch fills the chip, 2 whenever eligible (tests)
+  int graph = 1;         // CTN_GRAPH=0: every enqueue issues its launches one by one
+  int mfma_bk = 0;       // CTN_MFMA_BK=16|32: force the k-tile depth of k_mfma_f32
+  int splitk = -1;       // CTN_SPLITK: 0 disables the latency mode, 1 forces it for every eligible step (tests)
+  int splitk_max = 0;    // CTN_SPLITK_MAX: tile-count threshold of the latency mode
+  bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
+  const char* stamps = nullptr;  // CTN_DEBUG_STAMPS=<file> (make STAMPS=1 builds): dump in-kernel cycle stamps
+  int stamp_step = -1;   // CTN_DEBUG_STAMP_STEP=<s>: stamp only this step
+};
+static DevSwitches read_dev_switches() {
+  DevSwitches d;
+  auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+  d.mfma_g = num("CTN_MFMA_G", 1);
+  d.graph = num("CTN_GRAPH", 1);
+  const int bk = num("CTN_MFMA_BK", 0);
+  d.mfma_bk = (bk == 16 || bk == 32) ? bk : 0;
+  d.splitk = num("CTN_SPLITK", -1);
+  d.splitk_max = num("CTN_SPLITK_MAX", 0);
+  d.g_no_asm = getenv("CTN_G_NO_ASM") != nullptr;
+  d.stamps = getenv("CTN_DEBUG_STAMPS");
+  d.stamp_step = num("CTN_DEBUG_STAMP_STEP", -1);
+  return d;
+}
 
 #define HIPCHECK(expr)                                                                   \
   do {                                                                                   \
@@ -70,8 +96,8 @@ struct Exec {
   int R = 1;
   int n_tensors = 0;
   int n_cu = 256;
-  int mfma_g = 1;        // CTN_MFMA_G at creation time (see exec_launch_steps)
-  int mfma_g2 = 0;       // CTN_MFMA_G2 at creation time
+  DevSwitches sw;        // environment switches as they were when the executor was created
+  int mfma_g = 1;        // sw.mfma_g (see exec_launch_steps)
   // the launch sequence as a hipGraph (CTN_GRAPH, see exec_launch_all): captured on the second enqueue,
   // replayed afterwards; tensors are reached through the device pointer table, so new operands need no update
   int use_graph = 1;
@@ -151,18 +177,13 @@ static void launch_mfma_a(int ma, int mb, dim3 grid, hipStream_t st, const StepA
 // hides the per-tile prologue/epilogue best when K is short (MPS shapes: 108-118 TFLOP/s vs
 // 103-117 with BK = 32); BK = 32 halves the barriers per flop and wins on long-K GEMMs
 // (4096^3: 130 vs 115 TFLOP/s).  CTN_MFMA_BK=16|32 forces one of them (development knob).
-static int mfma_bk(int K) {
-  static int forced = [] {
-    const char* e = getenv("CTN_MFMA_BK");
-    const int v = e ? atoi(e) : 0;
-    return (v == 16 || v == 32) ? v : 0;
-  }();
-  if (forced) return forced;
+static int mfma_bk(int K, const DevSwitches& sw) {
+  if (sw.mfma_bk) return sw.mfma_bk;
   return K >= 2048 ? 32 : 16;
 }
 
-static void launch_mfma(int ma, int mb, int tile_n, dim3 grid, hipStream_t st, const StepArgs& a) {
-  const bool bk16 = mfma_bk(a.K) == 16;
+static void launch_mfma(int ma, int mb, int tile_n, dim3 grid, hipStream_t st, const StepArgs& a, const DevSwitches& sw) {
+  const bool bk16 = mfma_bk(a.K, sw) == 16;
   if (tile_n == 64) {
     if (bk16) launch_mfma_a<16, 64>(ma, mb, grid, st, a);
     else launch_mfma_a<32, 64>(ma, mb, grid, st, a);
@@ -175,11 +196,11 @@ static void launch_mfma(int ma, int mb, int tile_n, dim3 grid, hipStream_t st, c
 // Latency mode (see k_mfma_f32_sk): chosen when the 128-wide tiles of a step cannot occupy half the
 // chip.  Returns the number of K splits (0 = use the throughput kernel).  CTN_SPLITK=0 disables,
 // CTN_SPLITK=1 forces it for every eligible step (tests).
-static int splitk_splits(const Step& st, int R, int n_cu, int dtype) {
-  static const int mode = [] { const char* e = getenv("CTN_SPLITK"); return e ? atoi(e) : -1; }();
+static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
+  const int mode = sw.splitk;
   const bool mfma = (dtype == CTN_F32 && st.kernel == CTN_KERNEL_MFMA_F32) || (dtype == CTN_F64 && st.kernel == CTN_KERNEL_MFMA_F64);
   if (mode == 0 || !mfma || st.collapse || st.K < 128) return 0;
-  static const int max_tiles = [] { const char* e = getenv("CTN_SPLITK_MAX"); return e ? atoi(e) : 0; }();
+  const int max_tiles = sw.splitk_max;
   const int64_t limit = max_tiles > 0 ? max_tiles : n_cu / 2;
   if (mode != 1 && (int64_t)st.blocks * R > limit) return 0;
   const int64_t tiles64 = st.Bt * ((st.M + 63) / 64) * ((st.N + 63) / 64) * R;
@@ -338,7 +359,7 @@ static int exec_launch_steps(Exec* E) {
       case CTN_KERNEL_MFMA_F32: {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
-        if (const int S = E->d_slab ? splitk_splits(st, R, E->n_cu, P.dtype) : 0) {
+        if (const int S = E->d_slab ? splitk_splits(st, R, E->n_cu, P.dtype, E->sw) : 0) {
           SplitKArgs sk;
           sk.slab = E->d_slab;
           sk.numelC = P.tensors[st.out].numel;
@@ -354,8 +375,7 @@ static int exec_launch_steps(Exec* E) {
           break;
         }
         a.tiles_n = (int32_t)((st.N + st.tileN - 1) / st.tileN);
-        const char* stamp_step = getenv("CTN_DEBUG_STAMP_STEP");  // stamp only this step's launch
-        if (getenv("CTN_DEBUG_STAMPS") && (!stamp_step || atoi(stamp_step) == s)) {
+        if (E->sw.stamps && (E->sw.stamp_step < 0 || E->sw.stamp_step == s)) {
           if (E->dbg_tiles < (size_t)total) {
             if (E->d_dbg) (void)hipFree(E->d_dbg);
             HIPCHECK(hipMalloc((void**)&E->d_dbg, (size_t)total * 64));
@@ -366,13 +386,13 @@ static int exec_launch_steps(Exec* E) {
         }
         // large-tile LDS-DMA variant (kernels_mfma_g.h) where the step's shape allows it.
         // CTN_MFMA_G (read when the executor is created): 0 = never, 1 = 256x128 tiles when the launch
-        // fills the chip (default), 2 = whenever eligible (tests), 3 / 4 = the 256x256 experiments
+        // fills the chip (default), 2 = whenever eligible (tests)
         const int use_g = E->mfma_g;
         static_assert(GM == 256 && GN == kTileN && GK == 16 && 2 * GK == 32, "planner eligibility rule (plan.cpp) assumes these");
         // ... and the launch has at least two of the big tiles per CU: with fewer, 128-row tiles spread the
         // same work over more CUs (measured: 2048^3 runs at 90 vs 56 TFLOP/s, 4096^3 at 125 vs 135)
         const int64_t gtiles = st.Bt * ((st.M + GM - 1) / GM) * a.tiles_n * R;
-        static const bool no_asm = getenv("CTN_G_NO_ASM") != nullptr;   // development switch
+        const bool no_asm = E->sw.g_no_asm;
         const bool kcontig = st.modeA == 2 || st.modeB == 2;
         // ... and K >= 192: below that the 128-tile kernel's 3-4 workgroups per CU hide the per-tile cost
         // better (8192 x 8192 x K: K = 64 old +7 %, 128 +2 %, 192 equal, 256 large tiles +5 %)
@@ -396,25 +416,12 @@ static int exec_launch_steps(Exec* E) {
                                E->stream, a);
             break;
           }
-          if ((use_g == 3 || use_g == 4) && !kcontig && st.M % 256 == 0 && st.N % 256 == 0) {
-            used_tile(256, 256);
-            a.tiles_n = (int32_t)(st.N / 256);
-            a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
-            const dim3 g4((unsigned)((int64_t)a.blocks_per_replica * R));
-            if (use_g == 3 && st.K % GK == 0) hipLaunchKernelGGL((k_mfma_f32_g<8, 2, true>), g4, dim3(512), 0, E->stream, a);
-            else if (use_g == 3) hipLaunchKernelGGL((k_mfma_f32_g<8, 2>), g4, dim3(512), 0, E->stream, a);
-            else hipLaunchKernelGGL((k_mfma_f32_g<4, 4>), g4, dim3(256), 0, E->stream, a);
-          } else {
+          {
             used_tile(256, 128);
             a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
             const dim3 gg((unsigned)((int64_t)a.blocks_per_replica * R));
             // hand-scheduled blocks for whole k-tiles, the C++ loop (which masks a ragged last k-tile) otherwise
             const bool use_asm = st.K % GK == 0 && !no_asm;
-            // CTN_MFMA_G2=1 (experiment): two-stage ring, three workgroups per CU (kernels_mfma_g2.h)
-            if (E->mfma_g2 && use_asm && !kcontig) {
-              hipLaunchKernelGGL(k_mfma_f32_g2, gg, dim3(256), 0, E->stream, a);
-              break;
-            }
 #define CTN_G_LAUNCH(AA, BB)                                                                             \
             do {                                                                                         \
               if (use_asm) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, AA, BB>), gg, dim3(256), 0, E->stream, a); \
@@ -437,17 +444,17 @@ static int exec_launch_steps(Exec* E) {
           collapse_blocks = (int)(st.Bt * a.tiles_m * a.tiles_n);
           a.blocks_per_replica = collapse_blocks;
           a.partC_stride = collapse_blocks;
-          launch_mfma(st.modeA, st.modeB, 64, dim3((unsigned)((int64_t)collapse_blocks * R)), E->stream, a);
+          launch_mfma(st.modeA, st.modeB, 64, dim3((unsigned)((int64_t)collapse_blocks * R)), E->stream, a, E->sw);
           break;
         }
         used_tile(128, st.tileN);
-        launch_mfma(st.modeA, st.modeB, st.tileN, dim3((unsigned)total), E->stream, a);
+        launch_mfma(st.modeA, st.modeB, st.tileN, dim3((unsigned)total), E->stream, a, E->sw);
         break;
       }
       case CTN_KERNEL_MFMA_F64: {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
-        if (const int S = E->d_slab ? splitk_splits(st, R, E->n_cu, P.dtype) : 0) {   // latency mode, as in fp32
+        if (const int S = E->d_slab ? splitk_splits(st, R, E->n_cu, P.dtype, E->sw) : 0) {   // latency mode, as in fp32
           SplitKArgs sk;
           sk.slab = E->d_slab;
           sk.numelC = P.tensors[st.out].numel;
@@ -621,7 +628,7 @@ static int exec_launch_all(Exec* E) {
   const Plan& P = *E->plan;
   const bool timed = E->timing_runs < E->timing_slots;
   const bool chain = P.chain && E->d_chain != nullptr;
-  if (!E->use_graph || timed || chain || P.n_steps < 4 || E->eager_rescale || getenv("CTN_DEBUG_STAMPS")) return exec_launch_steps(E);
+  if (!E->use_graph || timed || chain || P.n_steps < 4 || E->eager_rescale || E->sw.stamps) return exec_launch_steps(E);
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(E->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
     (void)hipGetLastError();
@@ -794,9 +801,9 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   Exec& E = x->e;
   const Plan& P = plan->p;
   E.plan = &P; E.device = device; E.R = replicas; E.n_cu = n_cu > 0 ? n_cu : 256;
-  if (const char* g = getenv("CTN_MFMA_G")) E.mfma_g = atoi(g);
-  if (const char* g = getenv("CTN_GRAPH")) E.use_graph = atoi(g);
-  if (const char* g = getenv("CTN_MFMA_G2")) E.mfma_g2 = atoi(g) == 1;
+  E.sw = read_dev_switches();
+  E.mfma_g = E.sw.mfma_g;
+  E.use_graph = E.sw.graph;
   E.n_tensors = P.n_inputs + P.n_steps + 1;
   auto fail = [&](int code) { delete x; return code; };
 #define HIPCHECK_X(expr)                                                        \
@@ -820,7 +827,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   {
     size_t slab_elems = 0;   // split-K scratch: S slabs shaped like the step's output, per replica
     auto splits_of = [&](const Step& st) {
-      if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype)) return S;
+      if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw)) return S;
       if (const int S = dot_splits(st)) return S;
       if (const int S = stream_splits(st, replicas, E.n_cu)) return S;
       return rowdot_splits(st, replicas, E.n_cu);
@@ -841,7 +848,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   for (int s = 0; s < P.n_steps; ++s) {
     const Step& st = P.steps[s];
     E.step_partials[s] = st.partials;
-    if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
+    if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
                      rowdot_splits(st, replicas, E.n_cu)))
       E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxPartials, P.tensors[st.out].numel / 1024));
   }
@@ -907,7 +914,7 @@ int ctn_exec_enqueue(ctn_exec* exec, const void* const* dev_inputs, void* const*
 int ctn_exec_synchronize(ctn_exec* exec) {
   if (!exec) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
   HIPCHECK(hipStreamSynchronize(exec->e.stream));
-  if (const char* path = getenv("CTN_DEBUG_STAMPS")) {  // development only: dump the last MFMA launch's stamps
+  if (const char* path = exec->e.sw.stamps) {  // development only: dump the last MFMA launch's stamps
     Exec* E = &exec->e;
     if (E->d_dbg && E->dbg_tiles) {
       std::vector<unsigned long long> h(E->dbg_tiles * 8);

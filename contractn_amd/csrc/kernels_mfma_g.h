@@ -46,8 +46,6 @@ __device__ __forceinline__ void glds16(const float* g, float* lds) {
 // <NW waves, NJ 32-wide column blocks per wave>:
 //   <4, 2>: 256 x 128 tile, wave 128 x 64, 2 workgroups per CU
 //   <8, 2>: 256 x 256 tile, 8 waves as 2 x 4 of 128 x 64, 1 workgroup per CU
-//   <4, 4>: 256 x 256 tile, wave 128 x 128 (256 accumulator registers, one wave per SIMD): 8 LDS
-//           fragment reads per 16 MFMAs and a third less L2 -> LDS traffic per flop
 // ASM: the k-steps run as the hand-scheduled blocks of kernels_mfma_g_asm.inc (<4, 2> and K % 16 == 0 only)
 // MA / MB = 2: the operand is unit-stride along k instead ("mode 2", e.g. a row-major A): its 16-byte requests
 // run along k (one lane = one row, 4 consecutive k), its LDS image is [k / 4][rows][4], and both operands

@@ -37,7 +37,12 @@ def own_path(einstr, shapes, optimize="greedy"):
     return tuple(tuple(p) for p in find_path(terms, out, sizes, optimize))
 
 
+ONLY = set(sys.argv[1:])   # fixture names to (re)generate; none = all
+
+
 def save(name, tn, path, inputs=(), note=""):
+    if ONLY and name not in ONLY:
+        return
     einstr = tn.einsum_str
     params = tn.params
     np.seterr(all="ignore")
@@ -106,6 +111,13 @@ def main():
     save("mps_overlap_5x64x4_f32", tn, ssa_to_linear(ssa, 10), note="zipper path; MFMA-sized steps")
     tn, ssa = nets.mps_overlap(TN, 4, 48, 4, dtype=np.float64, seed=4)
     save("mps_overlap_4x48x4_f64", tn, ssa_to_linear(ssa, 8), note="zipper path")
+
+    # -- the same zipper with operands of extreme magnitude: every NORMALISED quantity stays in range (the reference
+    #    rescales each intermediate before the next product, einsum.py:387), products of un-normalised ones do not
+    #    (fp32: 4 x^2 * x * sqrt(K) leaves the range for x = 1e13 and sinks into the subnormals for x = 1e-14)
+    for mag, tag in ((1e13, "huge"), (1e-14, "tiny")):
+        tn, ssa = nets.mps_overlap(TN, 4, 32, 4, dtype=np.float32, seed=3, scale=1.0 / mag)
+        save(f"mps_overlap_4x32x4_f32_{tag}", tn, ssa_to_linear(ssa, 8), note=f"zipper path; entries ~ {mag:g}")
 
     # -- open MPS, random and all-ones (reference tests/test_einsum.py:28-64)
     tn = nets.mps_open(TN, (3, 5, 4), (2, 3, 2, 4), dtype=np.float64, seed=11)

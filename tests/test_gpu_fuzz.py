@@ -48,10 +48,7 @@ def test_random_pairwise_step(seed):
     assert np.max(np.abs(got - ref)) <= 1e-11 * scale, (einstr, sizes)
 
 
-@pytest.mark.parametrize("seed", range(40))
-def test_random_network(seed):
-    """3-6 operands, random shared labels (hyperedges allowed), auto path."""
-    rng = np.random.default_rng(OFFSET + 1000 + seed)
+def random_network_case(rng):
     n_ops = int(rng.integers(3, 7))
     labels = list(LETTERS[: int(rng.integers(3, 8))])
     sizes = {l: int(rng.choice([2, 3, 4, 6])) for l in labels}
@@ -62,7 +59,26 @@ def test_random_network(seed):
     present = sorted(set("".join(terms)))
     keep = [l for l in present if rng.random() < 0.35]
     rng.shuffle(keep)
-    einstr = ",".join(terms) + "->" + "".join(keep)
+    return ",".join(terms) + "->" + "".join(keep), sizes
+
+
+def random_pair_f32_case(rng):
+    pool = [1, 2, 4, 8, 12, 32, 40, 64, 100, 128]
+    sizes = {l: int(rng.choice(pool)) for l in "abcde"}
+    ta = "".join(rng.choice(list("abcde"), size=int(rng.integers(1, 4)), replace=False))
+    tb = "".join(rng.choice(list("abcde"), size=int(rng.integers(1, 4)), replace=False))
+    present = sorted(set(ta + tb))
+    keep = [l for l in present if rng.random() < 0.6]
+    rng.shuffle(keep)
+    return f"{ta},{tb}->{''.join(keep)}", sizes
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_network(seed):
+    """3-6 operands, random shared labels (hyperedges allowed), auto path."""
+    rng = np.random.default_rng(OFFSET + 1000 + seed)
+    einstr, sizes = random_network_case(rng)
+    terms = einstr.split("->")[0].split(",")
     ops = [rng.standard_normal([sizes[c] for c in t]) for t in terms]
     ref = np.einsum(einstr, *ops)
     t_hat, c = contract(einstr, *ops, split_format=True)
@@ -75,14 +91,8 @@ def test_random_network(seed):
 def test_random_pairwise_step_f32_larger(seed):
     """fp32 with extents that reach the MFMA / row-dot / vector-stream kernels."""
     rng = np.random.default_rng(OFFSET + 5000 + seed)
-    pool = [1, 2, 4, 8, 12, 32, 40, 64, 100, 128]
-    sizes = {l: int(rng.choice(pool)) for l in "abcde"}
-    ta = "".join(rng.choice(list("abcde"), size=int(rng.integers(1, 4)), replace=False))
-    tb = "".join(rng.choice(list("abcde"), size=int(rng.integers(1, 4)), replace=False))
-    present = sorted(set(ta + tb))
-    keep = [l for l in present if rng.random() < 0.6]
-    rng.shuffle(keep)
-    einstr = f"{ta},{tb}->{''.join(keep)}"
+    einstr, sizes = random_pair_f32_case(rng)
+    ta, tb = einstr.split("->")[0].split(",")
     ops = [rng.standard_normal([sizes[c] for c in t]).astype(np.float32) for t in (ta, tb)]
     ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
     t_hat, c = contract(einstr, *ops, split_format=True)

@@ -446,28 +446,6 @@ def test_graph_replay_matches_eager_and_follows_new_operands(monkeypatch):
     bc0.executor.close()
 
 
-@pytest.mark.parametrize("einstr,shapes", [
-    ("km,kn->mn", [(32, 256), (32, 128)]),              # one tile, two k-tiles (the ring's minimum)
-    ("km,kn->mn", [(256, 512), (256, 384)]),            # 2 x 3 tiles, 16 k-tiles: both stages reused 8 times
-    ("xkm,xkn->xmn", [(2, 48, 400), (2, 48, 200)]),     # batch label, ragged M and N
-])
-def test_two_stage_ring_variant(einstr, shapes, force_large_tiles, monkeypatch):
-    """CTN_MFMA_G2=1: the 256 x 128 kernel with a two-stage ring and three workgroups per CU (k_mfma_f32_g2)."""
-    monkeypatch.setenv("CTN_MFMA_G2", "1")
-    E.clear_caches()
-    rng = np.random.default_rng(41)
-    ops = [(rng.standard_normal(s) * rng.uniform(0.5, 3.0)).astype(np.float32) for s in shapes]
-    t_hat, c = contract(einstr, *ops, split_format=True)
-    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
-    got = t_hat.astype(np.float64) * np.exp(float(c))
-    assert np.max(np.abs(got - ref)) <= 2e-4 * np.max(np.abs(ref))
-    assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-5
-    monkeypatch.setenv("CTN_MFMA_G2", "0")
-    E.clear_caches()
-    t_ref, c_ref = contract(einstr, *ops, split_format=True)     # same k order per element: same bits as the 3-stage kernel
-    assert np.array_equal(t_hat, t_ref) and float(c) == float(c_ref)
-
-
 @pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-12)])
 @pytest.mark.parametrize("einstr,shapes", [
     ("abc,abc->", [(64, 64, 64), (64, 64, 64)]),          # the inner product that closes a network: 1 output, K = 262,144
@@ -588,3 +566,66 @@ def test_k_split_forms_with_replicas_in_flight():
                 terms = np.einsum(ein, *[np.abs(o).astype(np.float64) for o in sets[r]])
                 got = np.asarray(t[r], dtype=np.float64) * np.exp(float(c[r]))
                 assert np.max(np.abs(got - ref) / terms) <= tol, (ein, np.dtype(dtype).name, r)
+
+
+# ---- extreme magnitudes: the lazy epilogue rescale must not change what the reference computes -----------------
+def _plan_and_executor(g, dtype="float32", replicas=1):
+    shapes = tuple(o.shape for o in g["operands"])
+    clist = E._contract_path(g["einsum_str"], shapes, optimize=g["path"], memory_limit=None, use_blas=True)
+    plan = E._native_plan(clist, shapes, dtype)
+    return plan, engine.Executor(plan, replicas=replicas)
+
+
+def test_huge_operands_switch_the_executor_to_eager_rescale():
+    """fp32 operands of magnitude 1e13 (golden `mps_overlap_4x32x4_f32_huge`, generated by the reference): the
+    reference normalises every intermediate BEFORE the next product and stays finite (log-value 252.28).  A tile
+    kernel that accumulates on un-normalised operands overflows there (4e26 * 1e13 * sqrt(K) > 3.4e38); the executor
+    must notice it from the scale registers, repeat the contraction with eager rescaling, and report the
+    reference's value - never a silent inf."""
+    g = load_golden("mps_overlap_4x32x4_f32_huge")
+    plan, ex = _plan_and_executor(g)
+    assert any(i["kernel"] == 2 for i in plan.step_infos()), "the fixture must exercise the MFMA tile kernels"
+    outs, _log, resc = ex.run_host([g["operands"]])
+    assert ex.eager_reruns() == 1, "overflow of the lazy rescale was not detected"
+    assert np.all(np.isfinite(resc)) and np.all(np.isfinite(outs))
+    c = E.accumulate_log_scale(resc[0], np.dtype(np.float32))
+    assert float(outs[0]) == float(g["t_hat"]) and abs(float(c) - float(g["log_scale"])) <= 2e-5 * float(g["log_scale"])
+    # the executor stays eager: the next run needs no repeat and gives the same bits
+    outs2, _log2, resc2 = ex.run_host([g["operands"]])
+    assert ex.eager_reruns() == 1
+    np.testing.assert_array_equal(resc2, resc)
+    # forcing eager mode from the start is the same computation
+    plan2, ex2 = _plan_and_executor(g)
+    assert ex2.set_rescale_mode(1) == 0
+    outs3, _log3, resc3 = ex2.run_host([g["operands"]])
+    assert ex2.eager_reruns() == 0
+    np.testing.assert_array_equal(resc3, resc)
+    np.testing.assert_array_equal(outs3, outs)
+
+
+def test_eager_and_lazy_rescale_agree_on_ordinary_data():
+    """Eager mode is the reference's literal order of operations (T / s stored, then multiplied); on well-scaled
+    data the default lazy mode must agree with it to rounding, and must not trigger a repeat."""
+    for name, dtype, tol in (("mps_overlap_5x64x4_f32", "float32", 2e-6), ("mps_overlap_4x48x4_f64", "float64", 1e-14),
+                             ("cp_r48_f32", "float32", 2e-6), ("peps3x3_D2_f32", "float32", 2e-6)):
+        g = load_golden(name)
+        plan, lazy = _plan_and_executor(g, dtype)
+        _plan, eager = _plan_and_executor(g, dtype)
+        eager.set_rescale_mode(1)
+        o_l, _a, r_l = lazy.run_host([g["operands"]])
+        o_e, _b, r_e = eager.run_host([g["operands"]])
+        assert lazy.eager_reruns() == 0 and eager.eager_reruns() == 0
+        assert rel_err(o_l, o_e) <= 10 * tol, name
+        c_l = E.accumulate_log_scale(r_l[0], np.dtype(dtype))
+        c_e = E.accumulate_log_scale(r_e[0], np.dtype(dtype))
+        assert abs(float(c_l) - float(c_e)) <= tol * max(1.0, abs(float(c_e))) * 10, name
+        # the eager result against the golden (reference) as well
+        assert abs(float(c_e) - float(g["log_scale"])) <= (1e-10 if dtype == "float64" else 2e-5) * max(1.0, abs(float(g["log_scale"])))
+
+
+def test_underflowing_network_matches_the_reference_zero():
+    """Magnitude 1e-14: below the reference's min_norm threshold nothing is ever rescaled (einsum.py:94-102) and
+    the product underflows to an exact zero in the reference itself; same here, register untouched."""
+    g = load_golden("mps_overlap_4x32x4_f32_tiny")
+    t, c = contract(g["einsum_str"], *g["operands"], optimize=g["path"], split_format=True)
+    assert float(t) == 0.0 == float(g["t_hat"]) and float(c) == 0.0 == float(g["log_scale"])
