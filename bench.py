@@ -406,6 +406,10 @@ def run_peps(args, world, rank, local_rank, backend, dev):
         d["flops"] += info["flops"] * sc.R
         d["bytes"] += step_bytes[s_] * sc.R
         d["launches"] += 1
+    if args.dump_steps:
+        with open(args.dump_steps, "w") as fh:
+            json.dump([dict(info, ms=float(step_ms[s_]), bytes=step_bytes[s_], replicas=sc.R, tile=list(tiles[s_]),
+                            einsum=sc.bc.contract_list[s_][2]) for s_, info in enumerate(infos)], fh)
     dom_key = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
     dom = by_kernel[dom_key]
     mfma = dom_key[0] in (2, 3)
