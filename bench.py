@@ -45,6 +45,10 @@ def parse_args():
     ap.add_argument("--max-intermediate", type=int, default=None,
                     help="peps: slice until no intermediate has more elements than this")
     ap.add_argument("--workspace-gib", type=float, default=64.0, help="peps: workspace budget per GPU for slices in flight")
+    ap.add_argument("--no-peps", dest="with_peps", action="store_false",
+                    help="mps: skip the secondary PEPS strong-scaling measurement that follows the headline")
+    ap.add_argument("--peps-bonds", type=int, nargs="*", default=[8, 16], help="mps: bond dimensions of that secondary")
+    ap.add_argument("--peps-timeout", type=float, default=240.0, help="mps: watchdog for the secondary, seconds")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -119,11 +123,70 @@ def main():
     world, rank, local_rank, backend, dev = init_ranks(args)
     if args.config == "peps":
         result = run_peps(args, world, rank, local_rank, backend, dev)
+    else:
+        result = run_mps(args, world, rank, local_rank, backend, dev)
+        if args.with_peps and args.dtype == "f32":
+            peps_secondary(args, result, world, rank, local_rank, backend, dev)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def peps_secondary(args, result, world, rank, local_rank, backend, dev):
+    """After the headline measurement, the SAME launch also contracts the 8 x 8 PEPS of BASELINE config 5 sharded
+    over all its ranks (`--config peps` in short form: D = 8 with 64 slices, D = 16 with 256), so that a run at
+    N = 1, 2, 4, 8 GPUs leaves the strong-scaling figures of the index-sliced path next to the weak-scaling
+    headline.  It never endangers the headline line: errors are recorded in the object, and a watchdog thread
+    prints the line and ends the process if a rank gets stuck in a collective."""
+    import copy
+    import threading
+
+    import torch
+
+    torch.cuda.empty_cache()
+    out = result.setdefault("peps_strong_scaling", {}) if rank == 0 else {}
+
+    def give_up():
         if rank == 0:
-            print(json.dumps(result))
-        if world > 1:
-            dist.destroy_process_group()
-        return
+            out["error"] = f"watchdog: not finished after {args.peps_timeout:.0f}s"
+            print(json.dumps(result), flush=True)
+        os._exit(0 if rank == 0 else 3)
+
+    dog = threading.Timer(args.peps_timeout, give_up)
+    dog.daemon = True
+    dog.start()
+    try:
+        for bond, slices, max_int, steps, warmup in ((8, 64, None, 10, 2), (16, 64, 2 ** 28, 1, 1)):
+            if bond not in args.peps_bonds:
+                continue
+            a2 = copy.copy(args)
+            a2.rows, a2.cols, a2.bond, a2.slices, a2.max_intermediate = 8, 8, bond, slices, max_int
+            a2.steps, a2.warmup, a2.no_cpu_baseline, a2.dump_steps, a2.event_passes = steps, warmup, True, None, 1
+            try:
+                full = run_peps(a2, world, rank, local_rank, backend, dev)
+            except Exception as exc:  # noqa: BLE001 - recorded, the headline line must still be printed
+                full = {"error": repr(exc)}
+            if rank == 0:
+                keep = ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "achieved_tflops", "result", "error")
+                short = {k: full[k] for k in keep if k in full}
+                if "config" in full:
+                    short["config"] = {k: full["config"][k] for k in ("workload", "slices", "slices_per_gpu",
+                                                                      "work_overhead_vs_unsliced",
+                                                                      "flop_per_contraction_sliced")}
+                    r = full["roofline"]
+                    short["dominant_kernel"] = {k: r[k] for k in ("kernel", "bound", "achieved", "unit", "frac",
+                                                                  "share_of_device_time")}
+                out[f"D{bond}"] = short
+            torch.cuda.empty_cache()
+    finally:
+        dog.cancel()
+
+
+def run_mps(args, world, rank, local_rank, backend, dev):
+    """The BASELINE metric: R independent 100-site MPS overlaps per GPU and step (weak scaling)."""
+    import torch
+    import torch.distributed as dist
 
     from contractn_amd.einsum import BatchedContraction
 
@@ -300,10 +363,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(einstr, shapes, path, flat[0], offs, numels, args.cpu_seconds,
                                               float(t_hat[0]), float(logs[0]), f64)
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+    return result if rank == 0 else None
 
 
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E peak (spec)

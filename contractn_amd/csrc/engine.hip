@@ -155,21 +155,21 @@ struct Exec {
   }
 };
 
-template <int MA, int BK, int TN>
+template <int MA, int BK, int TN, int TM>
 static void launch_mfma_b(int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
   switch (mb) {
-    case 1: hipLaunchKernelGGL((k_mfma_f32<MA, 1, BK, TN>), grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((k_mfma_f32<MA, 2, BK, TN>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((k_mfma_f32<MA, 0, BK, TN>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((k_mfma_f32<MA, 1, BK, TN, TM>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_mfma_f32<MA, 2, BK, TN, TM>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_mfma_f32<MA, 0, BK, TN, TM>), grid, dim3(256), 0, st, a); break;
   }
 }
 
-template <int BK, int TN>
+template <int BK, int TN, int TM>
 static void launch_mfma_a(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
   switch (ma) {
-    case 1: launch_mfma_b<1, BK, TN>(mb, grid, st, a); break;
-    case 2: launch_mfma_b<2, BK, TN>(mb, grid, st, a); break;
-    default: launch_mfma_b<0, BK, TN>(mb, grid, st, a); break;
+    case 1: launch_mfma_b<1, BK, TN, TM>(mb, grid, st, a); break;
+    case 2: launch_mfma_b<2, BK, TN, TM>(mb, grid, st, a); break;
+    default: launch_mfma_b<0, BK, TN, TM>(mb, grid, st, a); break;
   }
 }
 
@@ -182,14 +182,18 @@ static int mfma_bk(int K, const DevSwitches& sw) {
   return K >= 2048 ? 32 : 16;
 }
 
-static void launch_mfma(int ma, int mb, int tile_n, dim3 grid, hipStream_t st, const StepArgs& a, const DevSwitches& sw) {
+// tile_m = 64: skinny rows (M <= 64 against a huge N) - always BK = 16 (these steps have a short K)
+static void launch_mfma(int ma, int mb, int tile_m, int tile_n, dim3 grid, hipStream_t st, const StepArgs& a, const DevSwitches& sw) {
   const bool bk16 = mfma_bk(a.K, sw) == 16;
-  if (tile_n == 64) {
-    if (bk16) launch_mfma_a<16, 64>(ma, mb, grid, st, a);
-    else launch_mfma_a<32, 64>(ma, mb, grid, st, a);
+  if (tile_m == 64) {
+    if (tile_n == 64) launch_mfma_a<16, 64, 64>(ma, mb, grid, st, a);
+    else launch_mfma_a<16, 128, 64>(ma, mb, grid, st, a);
+  } else if (tile_n == 64) {
+    if (bk16) launch_mfma_a<16, 64, 128>(ma, mb, grid, st, a);
+    else launch_mfma_a<32, 64, 128>(ma, mb, grid, st, a);
   } else {
-    if (bk16) launch_mfma_a<16, 128>(ma, mb, grid, st, a);
-    else launch_mfma_a<32, 128>(ma, mb, grid, st, a);
+    if (bk16) launch_mfma_a<16, 128, 128>(ma, mb, grid, st, a);
+    else launch_mfma_a<32, 128, 128>(ma, mb, grid, st, a);
   }
 }
 
@@ -335,7 +339,8 @@ static int exec_launch_steps(Exec* E) {
     a.Bt = (int32_t)st.Bt; a.M = (int32_t)st.M; a.N = (int32_t)st.N; a.K = (int32_t)st.K;
     a.idA = st.lhs; a.idB = st.rhs >= 0 ? st.rhs : E->n_tensors - 1; a.idC = st.out;
     a.n_tensors = E->n_tensors;
-    a.tiles_m = (int32_t)((st.M + kTileM - 1) / kTileM);
+    const int row_tile = (st.kernel == CTN_KERNEL_MFMA_F32 && st.tileM == 64) ? 64 : kTileM;
+    a.tiles_m = (int32_t)((st.M + row_tile - 1) / row_tile);
     a.tiles_n = (int32_t)((st.N + kTileN - 1) / kTileN);
     a.blocks_per_replica = st.blocks;
     a.R = R;
@@ -439,16 +444,16 @@ static int exec_launch_steps(Exec* E) {
         // leg): 128 x 64 tiles double the workgroups.  Only for steps whose partials go through the
         // collapse pass anyway (> 64 tiles per replica), where the tile count is not baked into the plan.
         if (st.collapse && st.tileN == kTileN && total < 2LL * E->n_cu && st.N > 64) {
-          used_tile(128, 64);
+          used_tile(row_tile, 64);
           a.tiles_n = (int32_t)((st.N + 63) / 64);
           collapse_blocks = (int)(st.Bt * a.tiles_m * a.tiles_n);
           a.blocks_per_replica = collapse_blocks;
           a.partC_stride = collapse_blocks;
-          launch_mfma(st.modeA, st.modeB, 64, dim3((unsigned)((int64_t)collapse_blocks * R)), E->stream, a, E->sw);
+          launch_mfma(st.modeA, st.modeB, row_tile, 64, dim3((unsigned)((int64_t)collapse_blocks * R)), E->stream, a, E->sw);
           break;
         }
-        used_tile(128, st.tileN);
-        launch_mfma(st.modeA, st.modeB, st.tileN, dim3((unsigned)total), E->stream, a, E->sw);
+        used_tile(row_tile, st.tileN);
+        launch_mfma(st.modeA, st.modeB, row_tile, st.tileN, dim3((unsigned)total), E->stream, a, E->sw);
         break;
       }
       case CTN_KERNEL_MFMA_F64: {

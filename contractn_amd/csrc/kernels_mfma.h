@@ -9,10 +9,12 @@
 namespace ctn {
 
 // ---------------------------------------------------------------------------
-// K-mfma-f32: 128 x TN workgroup tile (TN = 128 or 64), 4 waves (2x2), each wave
-// 64 x TN/2 = 2 x TN/64 v_mfma_f32_32x32x2_f32 accumulators, register-staged
-// double-buffered LDS, one barrier per k-tile.  TN = 64 serves skinny products
-// (boundary absorptions of 2D grids: N = 64) where a 128-wide tile would be half masked.
+// K-mfma-f32: TM x TN workgroup tile (TM, TN = 128 or 64), 4 waves (2x2), each wave
+// TM/2 x TN/2 = TM/64 x TN/64 v_mfma_f32_32x32x2_f32 accumulators, register-staged
+// double-buffered LDS, one barrier per k-tile.  TN = 64 / TM = 64 serve skinny products
+// (boundary absorptions of 2D grids: N = 64 or M = 64 against a huge other extent, 16 flop/B) where a
+// 128-wide tile would be half masked - these steps sit at the HBM ridge, and a half-masked tile makes them
+// matrix-pipe bound instead.
 //
 // MODE (per operand): 0 scalar gather, 1 float4 along the free index (LDS image
 // [k][rows]), 2 float4 along k (LDS image [rows][BK+1], odd row length => conflict-free
@@ -26,7 +28,6 @@ namespace ctn {
 // ---------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = kTileM;
 
 // Stages one ROWS x BK operand tile per k-step: global -> registers -> LDS.
 template <int MODE, int BK, int ROWS>
@@ -137,18 +138,19 @@ struct TileLoader {
   }
 };
 
-template <int MA, int MB, int BK, int TN, bool FULL>
+template <int MA, int MB, int BK, int TN, bool FULL, int BM>
 __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLoader<MB, BK, TN>& lb,
                                               const float* __restrict__ A, const float* __restrict__ B,
                                               const int32_t* __restrict__ okA, const int32_t* __restrict__ okB,
-                                              int K, float* sA, float* sB, f32x16 (&acc)[2][TN / 64], int tid,
+                                              int K, float* sA, float* sB, f32x16 (&acc)[BM / 64][TN / 64], int tid,
                                               unsigned long long* dbg1) {
   using LA = TileLoader<MA, BK, BM>;
   using LB = TileLoader<MB, BK, TN>;
   constexpr int SZA = LA::kSize, SZB = LB::kSize;
   constexpr int NJ = TN / 64;  // 32-wide column blocks per wave
+  constexpr int NI = BM / 64;  // 32-high row blocks per wave
   const int lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * 64, wn = (w & 1) * (TN / 2);
+  const int wm = (w >> 1) * (BM / 2), wn = (w & 1) * (TN / 2);
   const int l31 = lane & 31, h = lane >> 5;
 
   const int nkt = (K + BK - 1) / BK;
@@ -166,7 +168,9 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLo
 #endif
 
   // per-lane LDS fragment bases (element indices)
-  const int fa0 = LA::idx(wm + l31, h), fa1 = LA::idx(wm + 32 + l31, h);
+  int fax[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) fax[i] = LA::idx(wm + i * 32 + l31, h);
   int fbx[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) fbx[j] = LB::idx(wn + j * 32 + l31, h);
@@ -185,26 +189,28 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLo
     __builtin_amdgcn_sched_barrier(0);  // global loads stay in front of the MFMA phase
     const float* cA = sA + cur * SZA;
     const float* cB = sB + cur * SZB;
-    float fa[2][2], fb[2][NJ];
-    fa[0][0] = cA[fa0]; fa[0][1] = cA[fa1];
+    float fa[2][NI], fb[2][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) fa[0][i] = cA[fax[i]];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) fb[0][j] = cB[fbx[j]];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int c = kk & 1, nx = c ^ 1;
       if (kk + 1 < BK / 2) {
-        fa[nx][0] = cA[fa0 + (kk + 1) * stepA]; fa[nx][1] = cA[fa1 + (kk + 1) * stepA];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fa[nx][i] = cA[fax[i] + (kk + 1) * stepA];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) fb[nx][j] = cB[fbx[j] + (kk + 1) * stepB];
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
       // pin the interleave: the LDS reads of step kk+1 issue ahead of the MFMAs of step kk
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
     }
     __builtin_amdgcn_sched_barrier(0);  // the staged tile is consumed only after the MFMA phase
     if (more) {
@@ -217,17 +223,21 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLo
 
 // second launch-bound argument = waves per SIMD the register allocator must leave room for:
 // BK = 16 is sized for 3 workgroups per CU (<= 168 registers), BK = 32 for 2
-template <int MA, int MB, int BK, int TN>
+template <int MA, int MB, int BK, int TN, int BM = kTileM>
 __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a) {
+  static_assert((BM == 128 || BM == 64) && (TN == 128 || TN == 64), "tile shapes");
   using LA = TileLoader<MA, BK, BM>;
   using LB = TileLoader<MB, BK, TN>;
   constexpr int SZA = LA::kSize, SZB = LB::kSize;
   constexpr int NJ = TN / 64;
-  // one LDS object: [A buf0][A buf1][B buf0][B buf1][omC 128][onC TN][red 4 doubles]
-  __shared__ __attribute__((aligned(16))) float smem[2 * SZA + 2 * SZB + BM + TN + 8];
+  constexpr int NI = BM / 64;
+  // one LDS object: [A buf0][A buf1][B buf0][B buf1][omC BM][onC TN][red 4 doubles]; the operand buffers double as
+  // the epilogue's per-wave staging area (32 rows x TN/2 columns each), which for the 64-row tile is the larger of the two
+  constexpr int BUF = (2 * SZA + 2 * SZB > 4 * 32 * (TN / 2) ? 2 * SZA + 2 * SZB : 4 * 32 * (TN / 2) + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float smem[BUF + BM + TN + 8];
   float* sA = smem;
   float* sB = smem + 2 * SZA;
-  int* s_omC = reinterpret_cast<int*>(smem + 2 * SZA + 2 * SZB);
+  int* s_omC = reinterpret_cast<int*>(smem + BUF);
   int* s_onC = s_omC + BM;
   double* red = reinterpret_cast<double*>(s_onC + TN);
 
@@ -265,12 +275,12 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   lb.init(a.onB, n0, a.N, tid);
 
   const int lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * 64, wn = (w & 1) * (TN / 2);
+  const int wm = (w >> 1) * (BM / 2), wn = (w & 1) * (TN / 2);
   const int l31 = lane & 31, h = lane >> 5;
 
-  f32x16 acc[2][NJ];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -283,8 +293,8 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
 #endif
   // FULL: the tile lies completely inside M x N and K is a multiple of BK -> no masking
   const bool full = (m0 + BM <= a.M) && (n0 + TN <= a.N) && (a.K % BK == 0);
-  if (full) mfma_mainloop<MA, MB, BK, TN, true>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
-  else mfma_mainloop<MA, MB, BK, TN, false>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
+  if (full) mfma_mainloop<MA, MB, BK, TN, true, BM>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
+  else mfma_mainloop<MA, MB, BK, TN, false, BM>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 2] = __builtin_amdgcn_s_memtime();
 #endif
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
     // 128-256 contiguous bytes per store instruction).  No workgroup barrier is involved: LDS
     // operations of one wave execute in order, so the write -> read hand-off is wave-local.
     constexpr int WT = TN / 2;                       // columns owned by a wave
-    constexpr int LDSW = ((2 * SZA + 2 * SZB) / 4) & ~3;  // floats of LDS per wave (16-byte aligned)
+    constexpr int LDSW = (BUF / 4) & ~3;             // floats of LDS per wave (16-byte aligned)
     static_assert(LDSW >= 32 * WT, "per-wave staging area too small");
     constexpr int VW = WT / 4;                       // 16-byte vectors per row
     constexpr int RPI = 64 / VW;                     // rows covered by one wave-wide vector access
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
     const bool cin = n0 + gcol < a.N;  // N % 4 == 0 whenever c_vec, otherwise checked per element
     const int offn = s_onC[gcol];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll

@@ -243,7 +243,12 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     std::stable_sort(G[kN].begin(), G[kN].end(), by(false));
     bool aUnitInK = false, bUnitInK = false;
     for (auto* l : G[kK]) { if (l->inA && l->sA == 1) aUnitInK = true; if (l->inB && l->sB == 1) bUnitInK = true; }
-    std::stable_sort(G[kK].begin(), G[kK].end(), by(!(bUnitInK && !aUnitInK)));
+    // k order = memory order of the operand that is unit-stride along a contracted label; when both are, but along
+    // DIFFERENT labels, the larger operand decides (the other one falls back to 4-byte gathers: cheap for a 64 x 64
+    // boundary tensor, 1.4x the time of the whole step for the 2-million-element one)
+    bool kOrderA = !(bUnitInK && !aUnitInK);
+    if (aUnitInK && bUnitInK && rhs >= 0 && P.tensors[rhs].numel > P.tensors[lhs].numel) kOrderA = false;
+    std::stable_sort(G[kK].begin(), G[kK].end(), by(kOrderA));
 
     // -- output tensor and its layout
     Tensor out;
@@ -307,7 +312,10 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       st.kernel = CTN_KERNEL_MFMA_F32;
       // 64-wide column tiles when they cover N with less padding (e.g. N = 64, 192, 320)
       st.tileN = ((st.N + 63) / 64) * 64 < ((st.N + kTileN - 1) / kTileN) * kTileN ? 64 : kTileN;
-      st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + st.tileN - 1) / st.tileN));
+      // ... and 64-high row tiles likewise (M = 64 against a huge N: a PEPS boundary absorption seen from the
+      // other side; with 128-row tiles half of every MFMA and of every A load is padding)
+      st.tileM = ((st.M + 63) / 64) * 64 < ((st.M + kTileM - 1) / kTileM) * kTileM ? 64 : kTileM;
+      st.blocks = (int)(st.Bt * ((st.M + st.tileM - 1) / st.tileM) * ((st.N + st.tileN - 1) / st.tileN));
       // 256 x 128 tiles fed by LDS-DMA (kernels_mfma_g.h): each operand unit-stride along its free index
       // or along k (16-byte requests either way; not the general gather), at least two 16-deep k-tiles,
       // and M, N such that 256-row
@@ -317,8 +325,10 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       const int64_t pad256 = round_up(st.M, 256) * round_up(st.N, kTileN);
       if (st.modeA >= 1 && st.modeB >= 1 && st.tileN == kTileN && st.cvec && st.K >= 32 &&
           st.M > kTileM && pad256 * 100 <= pad128 * 115 &&
-          st.rhs >= 0 && P.tensors[st.lhs].numel <= (1LL << 30) && P.tensors[st.rhs].numel <= (1LL << 30))  // 32-bit byte offsets
+          st.rhs >= 0 && P.tensors[st.lhs].numel <= (1LL << 30) && P.tensors[st.rhs].numel <= (1LL << 30)) {  // 32-bit byte offsets
         st.tileM = 256;
+        st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + st.tileN - 1) / st.tileN));
+      }
     } else if (kEnableMfmaF64 && P.dtype == CTN_F64 && tileable) {
       st.kernel = CTN_KERNEL_MFMA_F64;
       st.tileN = kTile64N;

@@ -149,7 +149,11 @@ def test_planner_selects_large_tile_kernels():
     assert (i["kernel"], i["tile_m"], i["tile_n"]) == (3, 128, 128)
     # ragged M / N / K are fine as long as 256-row tiles do not pad much more than 128-row ones
     assert info("km,kn->mn", [(100, 400), (100, 200)], "float32")["tile_m"] == 256
-    assert info("km,kn->mn", [(100, 300), (100, 128)], "float32")["tile_m"] == 128      # 300 -> 512 rows: too much padding
+    assert info("km,kn->mn", [(100, 300), (100, 128)], "float32")["tile_m"] == 64       # 300 -> 512 rows: too much padding; 5 x 64 rows pad least
+    assert info("km,kn->mn", [(100, 384), (100, 128)], "float32")["tile_m"] == 128
+    # skinny rows against a long N (PEPS boundary absorption): 64-row tiles, no half-masked MFMAs
+    i = info("mk,kn->mn", [(64, 64), (64, 32768)], "float32")
+    assert (i["kernel"], i["tile_m"], i["tile_n"], i["blocks"]) == (2, 64, 128, 256)
     # a k-contiguous (row-major) operand is fine too, with any K
     assert info("mk,kn->mn", [(256, 256), (256, 1024)], "float32")["tile_m"] == 256
     assert info("mk,kn->mn", [(256, 40), (40, 1024)], "float32")["tile_m"] == 256
