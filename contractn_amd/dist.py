@@ -1,11 +1,14 @@
 """Multi-GPU execution of the contraction path: one process per GPU, RCCL over xGMI.
 
 The reference has no distributed layer at all.  The path
-shards in two ways:
+shards in three ways:
 
 * **replicas** - independent networks (same plan, different tensors) are dealt
   round-robin to the ranks; there is NO data-path collective
   (:func:`shard_range`; this is what ``bench.py --gpus N`` does);
+* **independent subtrees** - one network whose contraction tree is cut near the root: the subtrees are
+  dealt to the ranks, their (small) results are exchanged by ONE ``all_gather`` and every rank finishes
+  the top of the tree (:func:`contract_subtrees`; for networks with small cuts, e.g. PEPS with D <= 3);
 * **index slicing** - one network, a set S of contracted labels is fixed to each
   of its joint values in turn; every slice is an independent contraction with
   the same plan on sliced operands, slices are dealt to the ranks, each rank
@@ -306,6 +309,297 @@ def all_gather_combine(t_loc, c_loc, group=None, world=None, device=None):
         arr = buf.cpu().numpy()
         parts.append((arr[:-1].reshape(np.shape(t_loc)).astype(np.asarray(t_loc).dtype), arr[-1]))
     return combine_split(parts)
+
+
+# ---------------------------------------------------------------------------
+# independent subtrees (north_star: "independent subtrees of the contraction path shard across the GPUs of one
+# node with a single RCCL reduce/all-gather over xGMI at the join")
+# ---------------------------------------------------------------------------
+def subtree_plan(einstr, shapes, optimize="auto", n_parts=2, max_boundary=1 << 22):
+    """Cut the contraction tree of ``optimize`` into independent subtrees plus the top part that joins them.
+
+    The tree is opened from the root: the most expensive open node is replaced by its two children until there
+    are at least ``2 * n_parts`` open nodes (finer pieces balance better) or no node can be opened without an
+    open node's result exceeding ``max_boundary`` elements - the results are what crosses the links at the join,
+    so this mode is for networks whose cuts are small (a PEPS half has D^L boundary elements; fine
+    for D <= 3, hopeless for D >= 8 - those shard by index slicing, `SlicedContraction`).
+
+    Returns ``(parts, top)``:
+      parts[i] = dict(operands=[indices into the network's operands], einsum=..., path=linear path, cost=...,
+                      out=labels of the subtree's result)   - a single-operand part has ``path == ()``
+      top      = dict(einsum=..., path=linear path over the parts' results in order)
+    """
+    shapes = [tuple(int(d) for d in s) for s in shapes]
+    terms, out, sizes = paths.parse_einsum_input(einstr, shapes)
+    n = len(terms)
+    sets = [set(t) for t in terms]
+    if isinstance(optimize, str) or optimize is True:
+        # no tree given: a searched path is usually a sweep (a caterpillar tree has no balanced cut), so the
+        # operands are first split into balanced, weakly connected groups and each group gets its own path
+        groups = _partition_operands(sets, sizes, out, n_parts, max_boundary)
+        if len(groups) > 1:
+            how = "auto" if optimize is True else optimize
+            parts = []
+            for g in groups:
+                inside = set(g)
+                mine = set().union(*[sets[i] for i in g])
+                outside = set(out).union(*[sets[i] for i in range(n) if i not in inside])
+                lab = mine & outside
+                out_term = "".join([c for c in out if c in lab] + sorted(lab - set(out)))
+                sub_terms = [terms[i] for i in g]
+                sub_path = tuple(tuple(p) for p in paths.find_path(sub_terms, out_term, sizes, how)) if len(g) > 1 else ()
+                cst = paths.path_cost([set(t) for t in sub_terms], out_term, sizes, sub_path)[0] if len(g) > 1 else 0
+                parts.append({"operands": list(g), "einsum": ",".join(sub_terms) + "->" + out_term, "path": sub_path,
+                              "cost": cst, "out": out_term})
+            top_terms = [p["out"] for p in parts]
+            top = {"einsum": ",".join(top_terms) + "->" + out,
+                   "path": tuple(tuple(p) for p in paths.find_path(top_terms, out, sizes, how))}
+            return parts, top
+        lin = paths.find_path(terms, out, sizes, optimize)
+    else:
+        lin = optimize
+    # linear positions -> SSA tree
+    live = list(range(n))
+    children, leaves, cost = {}, {i: (i,) for i in range(n)}, {i: 0 for i in range(n)}
+    for num, step in enumerate(lin):
+        ids = [live[p] for p in sorted(step)]
+        for p in sorted(step, reverse=True):
+            live.pop(p)
+        new = n + num
+        if len(ids) == 1:        # unary step (trace / sum-out): stays with its operand's subtree
+            children[new] = (ids[0],)
+            leaves[new] = leaves[ids[0]]
+            cost[new] = cost[ids[0]]
+        else:
+            children[new] = tuple(ids)
+            leaves[new] = tuple(sorted(leaves[ids[0]] + leaves[ids[1]]))
+            joint = set().union(*[sets[i] for i in leaves[new]])
+            cost[new] = cost[ids[0]] + cost[ids[1]] + paths._size(
+                labels_of(ids[0], leaves, sets, out, n) | labels_of(ids[1], leaves, sets, out, n), sizes)
+            del joint
+        live.append(new)
+    root = live[0]
+
+    def out_size(node):
+        return paths._size(labels_of(node, leaves, sets, out, n), sizes)
+
+    open_nodes = [root]
+    while len(open_nodes) < 2 * n_parts:
+        cands = [x for x in open_nodes if x >= n and len(children[x]) == 2
+                 and all(out_size(c) <= max_boundary for c in children[x])]
+        if not cands:
+            break
+        pick = max(cands, key=lambda x: cost[x])
+        at = open_nodes.index(pick)
+        open_nodes[at:at + 1] = list(children[pick])
+    open_set = set(open_nodes)
+
+    def local_path(node_root, operand_ids):
+        """SSA steps below ``node_root`` (stopping at ``operand_ids``), renumbered over that operand list."""
+        local = {x: i for i, x in enumerate(operand_ids)}
+        steps = []
+
+        def walk(x):
+            if x in local:
+                return local[x]
+            kids = [walk(c) for c in children[x]]
+            local[x] = len(operand_ids) + len(steps)
+            steps.append(tuple(kids))
+            return local[x]
+
+        walk(node_root)
+        return paths.ssa_to_linear(steps, len(operand_ids)) if steps else ()
+
+    parts = []
+    for x in open_nodes:
+        ops = list(leaves[x])
+        lab = labels_of(x, leaves, sets, out, n)
+        # keep the caller's output order for labels that survive to the end, then the rest sorted
+        out_term = "".join([c for c in out if c in lab] + sorted(lab - set(out)))
+        parts.append({"operands": ops, "einsum": ",".join(terms[i] for i in ops) + "->" + out_term,
+                      "path": local_path(x, ops), "cost": cost[x], "out": out_term})
+    top = {"einsum": ",".join(p["out"] for p in parts) + "->" + out,
+           "path": local_path(root, open_nodes) if root not in open_set else ()}
+    return parts, top
+
+
+def _partition_operands(sets, sizes, out, n_parts, max_boundary):
+    """Balanced groups of operands with small cuts: recursive bisection of the network graph (operands joined by
+    shared labels) - a region grown breadth-first from a peripheral operand until it holds half the weight, then
+    boundary operands moved across while that shrinks the cut (weight = log2 of an operand's size; a group whose
+    open legs would exceed ``max_boundary`` elements is not split further).  Deterministic."""
+    import math
+
+    n = len(sets)
+    weight = [1.0 + math.log2(max(paths._size(s, sizes), 1)) for s in sets]
+    by_label = {}
+    for i, s in enumerate(sets):
+        for c in s:
+            by_label.setdefault(c, []).append(i)
+    nbrs = [sorted({j for c in sets[i] for j in by_label[c] if j != i}) for i in range(n)]
+
+    def boundary(group):
+        inside = set(group)
+        mine = set().union(*[sets[i] for i in group])
+        outside = set(out).union(*[sets[i] for i in range(n) if i not in inside])
+        return paths._size(mine & outside, sizes)
+
+    def bfs_order(group, start):
+        inside, seen, order, queue = set(group), {start}, [], [start]
+        while queue:
+            x = queue.pop(0)
+            order.append(x)
+            for y in nbrs[x]:
+                if y in inside and y not in seen:
+                    seen.add(y)
+                    queue.append(y)
+        return order + [x for x in group if x not in seen]     # disconnected leftovers last
+
+    def bisect(group):
+        far = bfs_order(group, group[0])[-1]                    # a peripheral operand
+        order = bfs_order(group, far)
+        total, acc, left = sum(weight[i] for i in group), 0.0, []
+        for x in order:
+            if acc >= total / 2 and left:
+                break
+            left.append(x)
+            acc += weight[x]
+        a, b = set(left), set(group) - set(left)
+        if not b:
+            return None
+        for _ in range(4):                                      # a few refinement sweeps
+            moved = False
+            for x in sorted(group):
+                src, dst = (a, b) if x in a else (b, a)
+                if len(src) <= 1:
+                    continue
+                wa = sum(weight[i] for i in a)
+                new_wa = wa - weight[x] if x in a else wa + weight[x]
+                if abs(new_wa - total / 2) > 0.15 * total + max(weight):
+                    continue
+                before = boundary(sorted(a)) * boundary(sorted(b))
+                src.discard(x)
+                dst.add(x)
+                if boundary(sorted(a)) * boundary(sorted(b)) < before:
+                    moved = True
+                else:
+                    dst.discard(x)
+                    src.add(x)
+            if not moved:
+                break
+        return sorted(a), sorted(b)
+
+    groups = [list(range(n))]
+    while len(groups) < n_parts:
+        cands = sorted((g for g in groups if len(g) > 1), key=lambda g: -sum(weight[i] for i in g))
+        done = False
+        for g in cands:
+            halves = bisect(g)
+            if halves and all(boundary(h) <= max_boundary for h in halves):
+                groups.remove(g)
+                groups.extend(halves)
+                done = True
+                break
+        if not done:
+            break
+    return sorted(groups)
+
+
+def labels_of(node, leaves, sets, out, n):
+    """Labels of a subtree's result: those of its leaves that are also needed outside it (or in the output)."""
+    inside = set(leaves[node])
+    mine = set().union(*[sets[i] for i in inside])
+    outside = set(out)
+    for i in range(n):
+        if i not in inside:
+            outside |= sets[i]
+    return mine & outside
+
+
+def assign_parts(costs, world):
+    """Longest-processing-time assignment of subtree costs to ranks; returns the rank of every part."""
+    load = [0] * world
+    owner = [0] * len(costs)
+    for i in sorted(range(len(costs)), key=lambda i: (-costs[i], i)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[i] = r
+        load[r] += costs[i]
+    return owner
+
+
+def contract_subtrees(einstr, operands, optimize="auto", contract_fn=None, group=None, rank=None, world=None,
+                      max_boundary=1 << 22, device=None, n_parts=None):
+    """Contract one network with its independent subtrees dealt to the ranks of ``group``; returns
+    ``(T_hat, log_scale)`` on every rank.
+
+    Every rank contracts the subtrees it owns (HIP engine unless ``contract_fn`` is injected), the results - in
+    split format, so nothing can overflow on the way - are exchanged by ONE ``all_gather`` of a packed buffer, and
+    every rank then runs the small top part of the tree on the gathered results: ``c = c_top + sum c_subtree``.
+    """
+    if contract_fn is None:
+        from .einsum import contract as contract_fn
+    dist = None
+    if world is None or rank is None:
+        try:
+            import torch.distributed as dist_mod
+
+            if dist_mod.is_available() and dist_mod.is_initialized():
+                dist = dist_mod
+                world, rank = dist.get_world_size(group), dist.get_rank(group)
+        except ImportError:
+            pass
+    if world is None:
+        world, rank = 1, 0
+    shapes = [np.shape(o) for o in operands]
+    parts, top = subtree_plan(einstr, shapes, optimize=optimize, n_parts=n_parts or world, max_boundary=max_boundary)
+    owner = assign_parts([p["cost"] for p in parts], world)
+    dtype = np.result_type(*[np.asarray(o).dtype for o in operands])
+    _, _, sizes = paths.parse_einsum_input(einstr, shapes)
+    numels = [int(np.prod([sizes[c] for c in p["out"]])) if p["out"] else 1 for p in parts]
+
+    results = [None] * len(parts)
+    for i, p in enumerate(parts):
+        if owner[i] != rank:
+            continue
+        ops = [operands[j] for j in p["operands"]]
+        if len(ops) == 1 and p["einsum"].split("->")[0] == p["out"]:
+            results[i] = (np.asarray(ops[0], dtype=dtype), 0.0)     # a bare operand: nothing to contract
+        else:
+            t, c = contract_fn(p["einsum"], *ops, optimize=p["path"] if len(ops) > 1 else "auto", split_format=True)
+            results[i] = (np.asarray(t), float(c))
+    if world > 1:
+        import torch
+
+        if dist is None:
+            import torch.distributed as dist
+        # one packed segment per rank: [T_hat of its parts ..., their log-scales ...], padded to the longest
+        seg = [sum(numels[i] + 1 for i in range(len(parts)) if owner[i] == r) for r in range(world)]
+        buf = np.zeros(max(seg), dtype=np.float64)
+        pos = 0
+        for i in range(len(parts)):
+            if owner[i] == rank:
+                buf[pos:pos + numels[i]] = np.asarray(results[i][0], dtype=np.float64).ravel()
+                buf[pos + numels[i]] = results[i][1]
+                pos += numels[i] + 1
+        backend = dist.get_backend(group)
+        dev = (torch.device("cuda", torch.cuda.current_device() if device is None else device)
+               if backend == "nccl" else torch.device("cpu"))
+        send = torch.from_numpy(buf).to(dev)
+        recv = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(recv, send, group=group)              # THE join
+        for r in range(world):
+            arr = recv[r].cpu().numpy()
+            pos = 0
+            for i in range(len(parts)):
+                if owner[i] == r:
+                    shp = tuple(sizes[c] for c in parts[i]["out"])
+                    results[i] = (arr[pos:pos + numels[i]].reshape(shp).astype(dtype), float(arr[pos + numels[i]]))
+                    pos += numels[i] + 1
+    c_sub = sum(c for _, c in results)
+    if len(parts) == 1:
+        return results[0][0], np.asarray(c_sub)
+    t, c = contract_fn(top["einsum"], *[t for t, _ in results], optimize=top["path"], split_format=True)
+    return t, np.asarray(float(c) + c_sub)
 
 
 def _hashable(optimize):

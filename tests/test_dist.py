@@ -164,3 +164,82 @@ def test_sliced_plan_is_cached_on_disk_and_validated(tmp_path):
         e, *o, path=list(first[1]), split_format=True))
     t_u, c_u = oracle_contract(tn.einsum_str, *ops)
     np.testing.assert_allclose(np.asarray(t_s) * np.exp(float(c_s)), np.asarray(t_u) * np.exp(float(c_u)), rtol=1e-10)
+
+
+# ---- independent subtrees ------------------------------------------------------------------------------------------
+def _oracle_on_path(einstr, *ops, optimize=None, split_format=True):
+    path = None if isinstance(optimize, str) or optimize is None else list(optimize)
+    return cpu_ref.contract(einstr, *ops, path=path, split_format=split_format)
+
+
+def test_subtree_plan_cuts_a_grid_into_balanced_parts_with_small_boundaries():
+    from contractn_amd import TN
+    from tests import networks as nets
+
+    tn = nets.peps_closed(TN, 4, 6, 3, dtype=np.float64, seed=6)
+    shapes = [o.shape for o in tn.params]
+    parts, top = D.subtree_plan(tn.einsum_str, shapes, n_parts=2)
+    assert len(parts) == 2 and sorted(i for p in parts for i in p["operands"]) == list(range(48))
+    assert all(len(p["out"]) <= 6 for p in parts)                      # at most one grid cut (+ nothing open)
+    assert max(p["cost"] for p in parts) <= 3 * min(p["cost"] for p in parts)
+    assert top["einsum"].endswith("->") and len(top["path"]) == 1
+    # an explicit path is cut along ITS tree: every part is a subtree of it, the top part joins them
+    from contractn_amd.paths import ssa_to_linear
+
+    row = ssa_to_linear(nets.peps_row_path(4, 6), 48)
+    parts_r, top_r = D.subtree_plan(tn.einsum_str, shapes, optimize=row, n_parts=2, max_boundary=3 ** 7)
+    assert sorted(i for p in parts_r for i in p["operands"]) == list(range(48))
+    t, c = D.contract_subtrees(tn.einsum_str, list(tn.params), optimize=row, contract_fn=_oracle_on_path,
+                               rank=0, world=1, n_parts=2, max_boundary=3 ** 7)
+    t_u, c_u = cpu_ref.contract(tn.einsum_str, *tn.params, path=row, split_format=True)
+    assert float(t) == float(t_u) and abs(float(c) - float(c_u)) <= 1e-12 * max(1.0, abs(float(c_u)))
+
+
+def test_assign_parts_balances_costs():
+    owner = D.assign_parts([10, 9, 3, 3, 2, 1], 2)
+    loads = [sum(c for c, o in zip([10, 9, 3, 3, 2, 1], owner) if o == r) for r in range(2)]
+    assert sorted(loads) == [14, 14]
+
+
+def _subtree_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from contractn_amd import TN
+    from tests import networks as nets
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tn = nets.peps_closed(TN, 4, 6, 3, dtype=np.float64, seed=6)
+        t, c = D.contract_subtrees(tn.einsum_str, list(tn.params), contract_fn=_oracle_on_path)
+        q.put((rank, float(t), float(c)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_subtree_join():
+    """Two ranks, each contracts the subtrees it owns, ONE all_gather of the packed results, top part on both."""
+    import torch.multiprocessing as mp
+
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_subtree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tn = nets.peps_closed(TN, 4, 6, 3, dtype=np.float64, seed=6)
+    t_u, c_u = cpu_ref.contract(tn.einsum_str, *tn.params, path=ssa_to_linear(nets.peps_row_path(4, 6), 48), split_format=True)
+    assert results[0][1:] == results[1][1:]
+    assert results[0][1] == float(t_u) and abs(results[0][2] - float(c_u)) <= 1e-11

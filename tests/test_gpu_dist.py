@@ -108,3 +108,50 @@ def test_bench_peps_two_ranks_rehearsal():
     # the same network, the same slices: the joined value does not depend on how many ranks shared the work
     assert line2["result"]["t_hat"] == line1["result"]["t_hat"]
     assert abs(line2["result"]["log_scale"] - line1["result"]["log_scale"]) <= 1e-5
+
+
+def _subtree_rank_main(rank, world, port, rows, cols, bond, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as tdist
+
+    from contractn_amd import TN, dist
+    from tests import networks as nets
+
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tn = nets.peps_closed(TN, rows, cols, bond, dtype=np.float32, seed=6)
+        t, c = dist.contract_subtrees(tn.einsum_str, list(tn.params), device=0)   # HIP engine on this rank's subtrees
+        q.put((rank, float(t), float(c)))
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_two_ranks_independent_subtrees_with_one_all_gather():
+    """north_star's second sharding mode: the 8 x 8 PEPS (D = 3: a cut has at most 3^12 elements) is split into
+    balanced groups of tensors, each rank contracts its groups on the engine, the small results cross in ONE
+    all_gather and both ranks finish the top of the tree - equal to the oracle's row sweep within 1e-3."""
+    import torch.multiprocessing as mp
+
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from oracle import cpu_ref
+    from tests import networks as nets
+
+    rows = cols = 8
+    tn = nets.peps_closed(TN, rows, cols, 3, dtype=np.float32, seed=6)
+    rt, rc = cpu_ref.contract(tn.einsum_str, *tn.params, path=ssa_to_linear(nets.peps_row_path(rows, cols), 128),
+                              split_format=True)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_subtree_rank_main, args=(r, 2, port, rows, cols, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert results[0][1:] == results[1][1:]
+    assert results[0][1] == float(rt) and abs(results[0][2] - float(rc)) <= 1e-3
