@@ -30,6 +30,7 @@
 #include "kernels_mfma.h"
 #include "kernels_mfma_g.h"
 #include "kernels_mfma_g64.h"
+#include "kernels_mfma_lat.h"
 #include "kernels_stream.h"
 
 namespace ctn {
@@ -47,6 +48,7 @@ struct DevSwitches {
   int mfma_bk = 0;       // CTN_MFMA_BK=16|32: force the k-tile depth of k_mfma_f32
   int splitk = -1;       // CTN_SPLITK: 0 disables the latency mode, 1 forces it for every eligible step (tests)
   int splitk_max = 0;    // CTN_SPLITK_MAX: tile-count threshold of the latency mode
+  int lat = -1;          // CTN_LAT: 0 never use the one-launch latency form (k_mfma_f32_lat), 1 whenever the shape allows (tests)
   bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
   const char* stamps = nullptr;  // CTN_DEBUG_STAMPS=<file> (make STAMPS=1 builds): dump in-kernel cycle stamps
   int stamp_step = -1;   // CTN_DEBUG_STAMP_STEP=<s>: stamp only this step
@@ -60,6 +62,7 @@ static DevSwitches read_dev_switches() {
   d.mfma_bk = (bk == 16 || bk == 32) ? bk : 0;
   d.splitk = num("CTN_SPLITK", -1);
   d.splitk_max = num("CTN_SPLITK_MAX", 0);
+  d.lat = num("CTN_LAT", -1);
   d.g_no_asm = getenv("CTN_G_NO_ASM") != nullptr;
   d.stamps = getenv("CTN_DEBUG_STAMPS");
   d.stamp_step = num("CTN_DEBUG_STAMP_STEP", -1);
@@ -213,6 +216,21 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSw
   return (int)S;
 }
 
+// One-launch latency form (k_mfma_f32_lat): K split over the eight waves of a workgroup instead of over
+// workgroups, no slabs and no reduce launch.  Returns the tile form Q (1: 32 x 32 tiles, 2: 64 x 64), 0 = not taken.
+// Same launch-size condition as split-K (the step's 128-wide tiles cannot occupy half the chip), at most 64 tiles
+// per replica (one abs-sum partial each), both k-offset tables in LDS, at most 256 MFMAs per wave.
+static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
+  if (sw.lat == 0 || dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.rhs < 0) return 0;
+  if (st.K > kLatMaxK || st.K < 32) return 0;
+  if (sw.lat != 1 && ((int64_t)st.blocks * R > n_cu / 2 || st.K < 128)) return 0;
+  const int64_t t32 = st.Bt * ((st.M + 31) / 32) * ((st.N + 31) / 32);
+  const int64_t t64 = st.Bt * ((st.M + 63) / 64) * ((st.N + 63) / 64);
+  if (t32 <= kMaxPartials && st.K <= 8 * 512) return 1;
+  if (t64 <= kMaxPartials && st.K <= 2 * 512) return 2;
+  return 0;
+}
+
 // the reduce pass of a split-K step: fold 16 to 1 while more than 16 slabs are left (ping-pong between the two
 // slab buffers), then the final pass (rescale, C, abs-sum partials)
 template <typename T>
@@ -364,6 +382,20 @@ static int exec_launch_steps(Exec* E) {
       case CTN_KERNEL_MFMA_F32: {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
+        if (const int Q = lat_form(st, R, E->n_cu, P.dtype, E->sw)) {
+          const int T = 32 * Q;
+          a.tiles_m = (int32_t)((st.M + T - 1) / T);
+          a.tiles_n = (int32_t)((st.N + T - 1) / T);
+          a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
+          a.partC = part_dst; a.partC_stride = kMaxPartials; reduced = true;   // one partial per tile, written directly
+          const int ks = Q == 1 ? 8 : 2;
+          const int kchunk = (int)(((st.K + ks - 1) / ks + 1) / 2 * 2);
+          used_tile(T, T);
+          const dim3 g((unsigned)((int64_t)a.blocks_per_replica * R));
+          if (Q == 1) hipLaunchKernelGGL(k_mfma_f32_lat<1>, g, dim3(512), 0, E->stream, a, kchunk);
+          else hipLaunchKernelGGL(k_mfma_f32_lat<2>, g, dim3(512), 0, E->stream, a, kchunk);
+          break;
+        }
         if (const int S = E->d_slab ? splitk_splits(st, R, E->n_cu, P.dtype, E->sw) : 0) {
           SplitKArgs sk;
           sk.slab = E->d_slab;
@@ -832,6 +864,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   {
     size_t slab_elems = 0;   // split-K scratch: S slabs shaped like the step's output, per replica
     auto splits_of = [&](const Step& st) {
+      if (lat_form(st, replicas, E.n_cu, P.dtype, E.sw)) return 0;
       if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw)) return S;
       if (const int S = dot_splits(st)) return S;
       if (const int S = stream_splits(st, replicas, E.n_cu)) return S;
@@ -853,6 +886,10 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   for (int s = 0; s < P.n_steps; ++s) {
     const Step& st = P.steps[s];
     E.step_partials[s] = st.partials;
+    if (const int Q = lat_form(st, replicas, E.n_cu, P.dtype, E.sw)) {
+      E.step_partials[s] = (int)(st.Bt * ((st.M + 32 * Q - 1) / (32 * Q)) * ((st.N + 32 * Q - 1) / (32 * Q)));
+      continue;
+    }
     if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
                      rowdot_splits(st, replicas, E.n_cu)))
       E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxPartials, P.tensors[st.out].numel / 1024));

@@ -1,0 +1,145 @@
+// kernels_mfma_lat.h - fp32 MFMA GEMM step for ONE network in flight: one launch, K split inside the workgroup
+// Part of the gfx950 contraction engine (see engine.hip for the overview).
+#pragma once
+#include "kernels_mfma.h"
+
+namespace ctn {
+
+// ---------------------------------------------------------------------------
+// K-mfma-f32-lat: LATENCY form of a GEMM step whose launch cannot fill the chip (a single mid-size network, a few
+// replicas: the loop of reference einsum.py:341-391 is a chain of dependent steps, so what counts is the time of
+// ONE step, not the rate).  The split-K form (k_mfma_f32_sk + k_splitk_reduce) spreads K over workgroups and
+// needs a second launch to add the slabs - two dependent launches per step, 12.6 us on the 100-site headline
+// network.  Here the K range is split over the EIGHT WAVES of one 512-thread workgroup instead:
+//
+//   Q = 1:  32 x 32 output tile, every wave one eighth of K        (K = 1024 steps: 64 MFMAs per wave)
+//   Q = 2:  64 x 64 output tile, four quadrant waves x two K halves (short K, wide outputs)
+//
+// A 32 x 32 block is exactly one v_mfma_f32_32x32x2_f32 accumulator, and with K split over the waves NO operand
+// element is used by two waves: fragments go straight from global memory (L2: the operands of such a step are a
+// few MB at most) into the MFMA operand registers, table-driven like every other kernel - no operand staging in
+// LDS, no barrier in the k loop.  LDS holds the k-offset tables (copied once, so a k-step's two table look-ups
+// are LDS reads instead of another dependent global round trip) and, after the loop, the eight partial
+// accumulators, which are added in wave order (fixed: bit-reproducible), rescaled lazily like every tile
+// kernel, stored, and summed into ONE abs-sum partial per tile (the launcher only takes this form when a replica
+// has at most 64 tiles, so consumers reduce the partials with one wave as usual).
+// ---------------------------------------------------------------------------
+constexpr int kLatMaxK = 4096;      // k-offset tables of both operands in LDS: 2 x 16 KiB
+
+template <int Q>
+__global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
+  constexpr int T = 32 * Q;            // tile edge
+  constexpr int KS = 8 / (Q * Q);      // K splits (waves per quadrant)
+  __shared__ int s_okA[kLatMaxK], s_okB[kLatMaxK];
+  __shared__ __attribute__((aligned(16))) float s_part[8][1024];   // one 32 x 32 partial per wave
+  __shared__ double red[8];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int pid = blockIdx.x;
+  const int r = pid / a.blocks_per_replica;        // here: T x T tiles per replica
+  const int t = pid - r * a.blocks_per_replica;
+  const int tiles_mn = a.tiles_m * a.tiles_n;
+  const int b = t / tiles_mn;
+  const int tt = t - b * tiles_mn;
+  const int m0 = (tt / a.tiles_n) * T, n0 = (tt % a.tiles_n) * T;
+  const int q = w % (Q * Q), ks = w / (Q * Q);     // quadrant and K split of this wave
+  const int qm = (q / Q) * 32, qn = (q % Q) * 32;
+
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
+  const float* __restrict__ B = (const float*)tp[a.idB] + a.obB[b];
+  float* __restrict__ C = (float*)tp[a.idC] + a.obC[b];
+
+  // everything that depends only on the step: requested first, consumed after the loop
+  const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
+  const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  // rows / columns beyond M / N read padded table entries (in bounds) and are dropped at the store
+  const int offA = a.omA[m0 + qm + l31], offB = a.onB[n0 + qn + l31];
+  for (int k = tid; k < a.K; k += 512) { s_okA[k] = a.okA[k]; s_okB[k] = a.okB[k]; }
+  __syncthreads();
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int kbeg = ks * kchunk, kend = min(a.K, kbeg + kchunk);   // kchunk is even; a wave may own nothing
+  const float* __restrict__ pa = A + offA;
+  const float* __restrict__ pb = B + offB;
+  // Rounds of 8 k-steps, software-pipelined over two register sets: the 16 gathers of round r + 1 (their table
+  // look-ups are LDS reads) are all in flight while the 8 MFMAs of round r issue, so a round costs one L2 round
+  // trip OR its matrix-pipe time, whichever is longer - not their sum per load, which is what a compiler-chosen
+  // interleave of loads and MFMAs gave.
+  float xa0[8], xb0[8], xa1[8], xb1[8];
+  auto LOAD = [&](float (&ya)[8], float (&yb)[8], int k0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      ya[u] = pa[s_okA[k0 + 2 * u + h]];
+      yb[u] = pb[s_okB[k0 + 2 * u + h]];
+    }
+  };
+  auto MMA = [&](const float (&ya)[8], const float (&yb)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u], yb[u], acc, 0, 0, 0);
+  };
+  const int nround = kend > kbeg ? (kend - kbeg) / 16 : 0;
+  int rd = 0;
+  if (nround > 0) LOAD(xa0, xb0, kbeg);
+  for (; rd + 2 <= nround; rd += 2) {
+    LOAD(xa1, xb1, kbeg + 16 * (rd + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    MMA(xa0, xb0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (rd + 2 < nround) LOAD(xa0, xb0, kbeg + 16 * (rd + 2));
+    __builtin_amdgcn_sched_barrier(0);
+    MMA(xa1, xb1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (rd < nround) MMA(xa0, xb0);
+  int k = kbeg + 16 * nround;
+  for (; k < kend; k += 2) {                                       // tail: masked k (a zero pair adds nothing)
+    const int kk = k + h;
+    const bool in = kk < kend;
+    const float xa = in ? pa[s_okA[kk]] : 0.f;
+    const float xb = in ? pb[s_okB[kk]] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, xb, acc, 0, 0, 0);
+  }
+
+  // the wave's partial block, [row][col] with 32-float rows: register e of lane (col, h) is row (e&3)+8(e>>2)+4h
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s_part[w][((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] = acc[e];
+  __syncthreads();
+
+  // every thread finishes T*T/512 elements: the KS partials of its quadrant in wave order, lazy rescale, store
+  const float iA = 1.0f / scA, iB = 1.0f / scB;
+  float asum = 0.f;
+#pragma unroll
+  for (int i = 0; i < T * T / 512; ++i) {
+    const int idx = tid + 512 * i;                 // element of the tile, column fastest
+    const int row = idx / T, col = idx % T;
+    const int qq = (row / 32) * Q + (col / 32);
+    const int off = (row % 32) * 32 + (col % 32);
+    float v = s_part[qq][off];
+#pragma unroll
+    for (int s = 1; s < KS; ++s) v += s_part[qq + s * Q * Q][off];
+    v = (v * iA) * iB;
+    if (m0 + row < a.M && n0 + col < a.N) {
+      C[a.omC[m0 + row] + a.onC[n0 + col]] = v;
+      asum += fabsf(v);
+    }
+  }
+  // fixed-order sum over the workgroup (8 waves)
+  double vsum = (double)asum;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) vsum += __shfl_xor(vsum, o, 64);
+  if (lane == 0) red[w] = vsum;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += red[i];
+    a.partC[(size_t)r * a.partC_stride + t] = tot;
+  }
+}
+
+}  // namespace ctn

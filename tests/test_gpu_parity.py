@@ -370,9 +370,12 @@ def test_launcher_retiles_by_replica_count():
     ("km,kn->mn", [(19200, 64), (19200, 64)]),          # 300 slabs: folded 16 to 1 twice (300 -> 19 -> 2)
     ("km,kn->mn", [(2304, 65), (2304, 33)]),            # 36 slabs of an odd element count: scalar fold
 ])
-def test_latency_mode_split_k(dtype, tol, einstr, shapes):
+def test_latency_mode_split_k(dtype, tol, einstr, shapes, monkeypatch):
     """One small network: 64 x 64 tiles with K split over workgroups and a fixed-order slab reduction,
-    in fp32 and in fp64 (ctn_exec_step_tile reports the 64 x 64 kernel)."""
+    in fp32 and in fp64 (ctn_exec_step_tile reports the 64 x 64 kernel).  (fp32 steps with at most 64 small tiles
+    take the one-launch form by default - test_latency_mode_one_launch; here it is switched off.)"""
+    monkeypatch.setenv("CTN_LAT", "0")
+    E.clear_caches()
     rng = np.random.default_rng(5)
     ops = [rng.standard_normal(s).astype(dtype) for s in shapes]
     bc = E.BatchedContraction(einstr, shapes, dtype, optimize=((0, 1),), replicas=1)
@@ -384,6 +387,54 @@ def test_latency_mode_split_k(dtype, tol, einstr, shapes):
     assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)) * 10
     t2, c2 = contract(einstr, *ops, split_format=True)      # bit-reproducible: same reduction order every time
     assert np.array_equal(t2, t[0]) and float(c2) == float(c[0])
+    E.clear_caches()
+
+
+@pytest.mark.parametrize("einstr,shapes,tile", [
+    ("mk,kn->mn", [(256, 1024), (1024, 256)], (32, 32)),      # the MPS environment step: 64 tiles, 128 k per wave
+    ("km,kn->mn", [(256, 256), (256, 1024)], (64, 64)),       # the other zipper step: 64 tiles of 64 x 64, two K halves
+    ("km,kn->mn", [(300, 70), (300, 100)], (32, 32)),         # ragged M, N and K (k chunks of 38: tail rounds)
+    ("mk,nk->mn", [(130, 200), (90, 200)], (32, 32)),         # both k-contiguous, ragged tiles
+    ("xkm,xkn->xmn", [(2, 160, 64), (2, 160, 96)], (32, 32)),  # batch label: 2 x 2 x 3 tiles
+    ("kam,kbn->ambn", [(136, 4, 24), (136, 2, 40)], (32, 32)),  # composite free indices, strided C
+    ("km,kn->mn", [(4096, 64), (4096, 64)], (32, 32)),        # K = 4096: both tables fill their LDS arrays
+    ("km,kn->mn", [(130, 512), (130, 400)], (64, 64)),        # 8 x 7 tiles of 64: odd k chunk (65 -> 66)
+])
+def test_latency_mode_one_launch(einstr, shapes, tile):
+    """One network in flight, fp32: the step runs as ONE launch of k_mfma_f32_lat - K split over the eight waves of
+    a workgroup, partials added in wave order in LDS - instead of split-K slabs plus a reduce launch."""
+    rng = np.random.default_rng(6)
+    ops = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    bc = E.BatchedContraction(einstr, shapes, np.float32, optimize=((0, 1),), replicas=1)
+    t, c = bc.run_host([ops])
+    assert bc.executor.step_tiles() == [tile]
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    got = t[0].astype(np.float64) * np.exp(float(c[0]))
+    assert np.max(np.abs(got - ref)) <= 2e-4 * np.max(np.abs(ref))
+    assert abs(np.mean(np.abs(t[0])) - 1.0) < 1e-5
+    t2, c2 = bc.run_host([ops])                              # fixed reduction order: the same bits every time
+    assert np.array_equal(t2, t) and np.array_equal(c2, c)
+    bc.executor.close()
+    # small exact integers: every product and partial sum is exact, so the result is NumPy's bit for bit
+    iops = [rng.integers(-3, 4, size=s).astype(np.float32) for s in shapes]
+    ti, ci = contract(einstr, *iops, split_format=True)
+    refi = np.einsum(einstr, *[o.astype(np.float64) for o in iops])
+    np.testing.assert_allclose(ti.astype(np.float64) * np.exp(float(ci)), refi, rtol=1e-6, atol=1e-6 * np.max(np.abs(refi)))
+
+
+def test_latency_mode_feeds_rescaled_intermediates(monkeypatch):
+    """A chain of latency-form steps (forced also for its short-K steps): every step consumes its predecessor's
+    un-normalised output and abs-sum partials (one per tile) exactly like the throughput kernels' outputs."""
+    monkeypatch.setenv("CTN_LAT", "1")
+    E.clear_caches()
+    g = load_golden("mps_overlap_5x64x4_f32")
+    plan, ex = _plan_and_executor(g)
+    outs, _log, resc = ex.run_host([g["operands"]])
+    tiles = ex.step_tiles()
+    assert sum(t == (32, 32) for t in tiles) >= 6, tiles
+    c = E.accumulate_log_scale(resc[0], np.dtype(np.float32))
+    assert float(outs[0]) == float(g["t_hat"]) and abs(float(c) - float(g["log_scale"])) <= 2e-5 * abs(float(g["log_scale"]))
+    E.clear_caches()
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
