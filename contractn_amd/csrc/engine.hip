@@ -117,7 +117,11 @@ struct Exec {
   double* d_scratch = nullptr;
   void* d_slab = nullptr;           // split-K partial tiles (latency mode), sized at creation
   void* d_slab2 = nullptr;          // 1/16 of it: where more than 16 slabs are folded 16 to 1 (k_splitk_fold)
-  std::vector<int> step_partials;   // abs-sum partials per replica of every step (plan value unless split-K)
+  std::vector<int> step_partials;   // abs-sum partials per replica of every step (plan value unless split-K / latency form)
+  std::vector<int64_t> step_off;    // d_partials: step s, replica r at (step_off[s] * R + r * step_partials[s]) doubles
+  int64_t part_slots = 0;           // sum of the steps' slots
+  int64_t* d_stepOff = nullptr;
+  int32_t* d_stepSlots = nullptr;
   double* d_log = nullptr;
   double* d_resc = nullptr;
   double* d_logs = nullptr;
@@ -149,6 +153,7 @@ struct Exec {
     DeviceGuard dg(device);
     for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch, (void*)d_slab, (void*)d_slab2,
                     (void*)d_log, (void*)d_resc, (void*)d_logs, (void*)d_chain, d_ones, (void*)d_stepP, (void*)d_stepNumel,
+                    (void*)d_stepOff, (void*)d_stepSlots,
                     (void*)d_stage_in, (void*)d_stage_out})
       if (p) (void)hipFree(p);
     if (h_pack) (void)hipHostFree(h_pack);
@@ -226,8 +231,8 @@ static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitche
   if (sw.lat != 1 && ((int64_t)st.blocks * R > n_cu / 2 || st.K < 128)) return 0;
   const int64_t t32 = st.Bt * ((st.M + 31) / 32) * ((st.N + 31) / 32);
   const int64_t t64 = st.Bt * ((st.M + 63) / 64) * ((st.N + 63) / 64);
-  if (t32 <= kMaxPartials && st.K <= 8 * 512) return 1;
-  if (t64 <= kMaxPartials && st.K <= 2 * 512) return 2;
+  if (t32 <= kWaveOutputs && st.K <= 8 * 512) return 1;
+  if (t64 <= kWaveOutputs && st.K <= 2 * 512) return 2;
   return 0;
 }
 
@@ -337,20 +342,21 @@ static int exec_launch_steps(Exec* E) {
     a.onB = T + st.t.onB; a.onC = T + st.t.onC;
     a.okA = T + st.t.okA; a.okB = T + st.t.okB;
     a.ptrs = E->d_ptrs;
-    auto part_of = [&](int id, const double** p, int32_t* cnt, double* numel) {
-      *p = nullptr; *cnt = 0; *numel = 1;
+    auto part_of = [&](int id, const double** p, int32_t* cnt, int32_t* stride, double* numel) {
+      *p = nullptr; *cnt = 0; *stride = 0; *numel = 1;
       if (id >= P.n_inputs && P.stabilize && !E->eager_rescale) {
         const int ps = P.tensors[id].producer;
-        *p = E->d_partials + (size_t)ps * R * kMaxPartials;
-        *cnt = E->step_partials[ps];
+        *p = E->d_partials + (size_t)E->step_off[ps] * R;
+        *cnt = *stride = E->step_partials[ps];
         *numel = (double)P.tensors[id].numel;
       }
     };
-    part_of(st.lhs, &a.partA, &a.PA, &a.numelA);
-    part_of(st.rhs, &a.partB, &a.PB, &a.numelB);
-    double* part_dst = E->d_partials + (size_t)s * R * kMaxPartials;
+    part_of(st.lhs, &a.partA, &a.PA, &a.strideA, &a.numelA);
+    part_of(st.rhs, &a.partB, &a.PB, &a.strideB, &a.numelB);
+    double* part_dst = E->d_partials + (size_t)E->step_off[s] * R;
+    const int part_stride = E->step_partials[s];    // slots per replica of this step's region
     a.partC = st.collapse ? E->d_scratch : part_dst;
-    a.partC_stride = st.collapse ? st.blocks : kMaxPartials;
+    a.partC_stride = st.collapse ? st.blocks : part_stride;
     int collapse_blocks = st.blocks;   // partials written per replica when the step collapses (a launcher may retile)
     bool reduced = false;              // a K-split streaming / row-dot step: its reduce pass wrote the partials itself
     a.min_norm = P.min_norm;
@@ -387,7 +393,7 @@ static int exec_launch_steps(Exec* E) {
           a.tiles_m = (int32_t)((st.M + T - 1) / T);
           a.tiles_n = (int32_t)((st.N + T - 1) / T);
           a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
-          a.partC = part_dst; a.partC_stride = kMaxPartials; reduced = true;   // one partial per tile, written directly
+          a.partC = part_dst; a.partC_stride = part_stride; reduced = true;   // one partial per tile, written directly
           const int ks = Q == 1 ? 8 : 2;
           const int kchunk = (int)(((st.K + ks - 1) / ks + 1) / 2 * 2);
           used_tile(T, T);
@@ -566,7 +572,7 @@ static int exec_launch_steps(Exec* E) {
         if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_rowdot<float>, g, dim3(256), 0, E->stream, a);
         else hipLaunchKernelGGL(k_rowdot<double>, g, dim3(256), 0, E->stream, a);
         if (ks) {
-          a.partC = part_dst; a.partC_stride = kMaxPartials; reduced = true;
+          a.partC = part_dst; a.partC_stride = part_stride; reduced = true;
           if (P.dtype == CTN_F32) launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
           else launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
         }
@@ -607,7 +613,7 @@ static int exec_launch_steps(Exec* E) {
         }
 #undef CTN_STREAM
         if (ks) {
-          a.partC = part_dst; a.partC_stride = kMaxPartials; reduced = true;
+          a.partC = part_dst; a.partC_stride = part_stride; reduced = true;
           if (P.dtype == CTN_F32) launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
           else launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
         }
@@ -622,16 +628,18 @@ static int exec_launch_steps(Exec* E) {
       const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / V + 255) / 256, 2048)), R);
       if (P.dtype == CTN_F32)
         hipLaunchKernelGGL(k_renorm<float>, g, dim3(256), 0, E->stream, (void* const*)E->d_ptrs, E->n_tensors, st.out, numel,
-                           (const double*)part_dst, E->step_partials[s], P.min_norm);
+                           (const double*)part_dst, E->step_partials[s], part_stride, P.min_norm);
       else
         hipLaunchKernelGGL(k_renorm<double>, g, dim3(256), 0, E->stream, (void* const*)E->d_ptrs, E->n_tensors, st.out, numel,
-                           (const double*)part_dst, E->step_partials[s], P.min_norm);
+                           (const double*)part_dst, E->step_partials[s], part_stride, P.min_norm);
     }
     if (timed) HIPCHECK(hipEventRecord(E->events[ev0 + 1], E->stream));
   }
   FinalArgs f;
   f.ptrs = E->d_ptrs;
   f.partials = E->d_partials;
+  f.stepOff = E->d_stepOff;
+  f.stepSlots = E->d_stepSlots;
   f.stepP = E->d_stepP;
   f.stepNumel = E->d_stepNumel;
   f.log_scale = E->d_log;
@@ -797,7 +805,9 @@ int64_t ctn_plan_out_bytes(const ctn_plan* plan) {
 
 static int64_t exec_fixed_bytes(const Plan& P, int R) {
   const int nt = P.n_inputs + P.n_steps + 1;
-  return (int64_t)P.tables.size() * 4 + (int64_t)R * nt * 8 + (int64_t)P.n_steps * R * kMaxPartials * 8 +
+  int64_t slots = 0;
+  for (const Step& st : P.steps) slots += std::max(st.partials, kWaveOutputs);   // (a launcher may retile: upper bound)
+  return (int64_t)P.tables.size() * 4 + (int64_t)R * nt * 8 + slots * R * 8 +
          (int64_t)R * std::max<int64_t>(P.max_collapse_blocks, 1) * 8 + (int64_t)R * 8 +
          (int64_t)R * P.n_steps * 8 + 256 + (int64_t)P.n_steps * 12;
 }
@@ -858,8 +868,6 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   HIPCHECK_X(hipMalloc((void**)&E.d_tables, std::max<size_t>(P.tables.size(), 4) * 4));
   HIPCHECK_X(hipMemcpy(E.d_tables, P.tables.data(), P.tables.size() * 4, hipMemcpyHostToDevice));
   HIPCHECK_X(hipMalloc((void**)&E.d_ptrs, (size_t)replicas * E.n_tensors * sizeof(void*)));
-  HIPCHECK_X(hipMalloc((void**)&E.d_partials, (size_t)P.n_steps * replicas * kMaxPartials * 8));
-  HIPCHECK_X(hipMemset(E.d_partials, 0, (size_t)P.n_steps * replicas * kMaxPartials * 8));
   HIPCHECK_X(hipMalloc((void**)&E.d_scratch, (size_t)replicas * std::max<int64_t>(P.max_collapse_blocks, 1) * 8));
   {
     size_t slab_elems = 0;   // split-K scratch: S slabs shaped like the step's output, per replica
@@ -881,18 +889,29 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
           fold_elems = std::max(fold_elems, (size_t)((S + 15) / 16) * (size_t)P.tensors[st.out].numel * (size_t)replicas);
     if (fold_elems) HIPCHECK_X(hipMalloc((void**)&E.d_slab2, fold_elems * (P.dtype == CTN_F64 ? 8 : 4)));
   }
-  // partial counts: the split-K reduce pass spreads over up to 64 workgroups per replica
+  // partial counts: plan value, one per tile in the latency form, and the split-K reduce pass spreads over up to
+  // 64 workgroups per replica; every step gets a region of exactly that many slots per replica
   E.step_partials.resize(P.n_steps);
+  E.step_off.resize(P.n_steps);
   for (int s = 0; s < P.n_steps; ++s) {
     const Step& st = P.steps[s];
-    E.step_partials[s] = st.partials;
-    if (const int Q = lat_form(st, replicas, E.n_cu, P.dtype, E.sw)) {
+    E.step_partials[s] = std::max(st.partials, 1);
+    if (const int Q = lat_form(st, replicas, E.n_cu, P.dtype, E.sw))
       E.step_partials[s] = (int)(st.Bt * ((st.M + 32 * Q - 1) / (32 * Q)) * ((st.N + 32 * Q - 1) / (32 * Q)));
-      continue;
-    }
-    if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
-                     rowdot_splits(st, replicas, E.n_cu)))
-      E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxPartials, P.tensors[st.out].numel / 1024));
+    else if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
+                          rowdot_splits(st, replicas, E.n_cu)))
+      E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kWaveOutputs, P.tensors[st.out].numel / 1024));
+    E.step_off[s] = E.part_slots;
+    E.part_slots += E.step_partials[s];
+  }
+  HIPCHECK_X(hipMalloc((void**)&E.d_partials, (size_t)E.part_slots * replicas * 8));
+  HIPCHECK_X(hipMemset(E.d_partials, 0, (size_t)E.part_slots * replicas * 8));
+  {
+    std::vector<int32_t> slots(E.step_partials.begin(), E.step_partials.end());
+    HIPCHECK_X(hipMalloc((void**)&E.d_stepOff, P.n_steps * 8));
+    HIPCHECK_X(hipMalloc((void**)&E.d_stepSlots, P.n_steps * 4));
+    HIPCHECK_X(hipMemcpy(E.d_stepOff, E.step_off.data(), P.n_steps * 8, hipMemcpyHostToDevice));
+    HIPCHECK_X(hipMemcpy(E.d_stepSlots, slots.data(), P.n_steps * 4, hipMemcpyHostToDevice));
   }
   HIPCHECK_X(hipMalloc((void**)&E.d_log, (size_t)replicas * 8));
   HIPCHECK_X(hipMalloc((void**)&E.d_resc, (size_t)replicas * P.n_steps * 8));

@@ -36,7 +36,7 @@ static FastDiv make_fastdiv(int64_t d64) {
 struct StepArgs {
   const int32_t *obA, *obB, *obC, *omA, *omC, *onB, *onC, *okA, *okB;
   void* const* ptrs;    // [R][n_tensors] base pointer of every tensor of every replica
-  const double* partA;  // [R][64] abs-sum partials of A's producer step, nullptr for inputs
+  const double* partA;  // [R][strideA] abs-sum partials of A's producer step (PA of them are valid), nullptr for inputs
   const double* partB;
   double* partC;        // [R][partC_stride] where this step's partials go
   double numelA, numelB;
@@ -44,6 +44,7 @@ struct StepArgs {
   int32_t Bt, M, N, K;
   int32_t idA, idB, idC, n_tensors;
   int32_t PA, PB;
+  int32_t strideA, strideB;  // slots per replica in partA / partB (>= PA / PB)
   int32_t partC_stride;
   int32_t tiles_m, tiles_n;
   int32_t blocks_per_replica;
@@ -63,8 +64,10 @@ struct StepArgs {
 
 struct FinalArgs {
   void* const* ptrs;
-  const double* partials;   // [n_steps][R][64]
-  const int32_t* stepP;     // [n_steps] partial count of each step
+  const double* partials;   // step s, replica r: partials + stepOff[s] * R + r * stepSlots[s]
+  const int64_t* stepOff;   // [n_steps] offset of each step's region, in doubles per replica
+  const int32_t* stepSlots; // [n_steps] slots per replica of each step's region
+  const int32_t* stepP;     // [n_steps] partial count of each step (<= its slots)
   const double* stepNumel;  // [n_steps] numel of each step's output
   double* log_scale;        // [R]
   double* rescales;         // [R][n_steps]
@@ -80,14 +83,17 @@ struct FinalArgs {
 // einsum.py:97-102: norm = sum|T|, rescale = norm / numel, applied iff
 // norm > min_norm).  All 64 lanes of the calling wave must be active.
 template <typename T>
-__device__ __forceinline__ T producer_scale(const double* part, int P, double numel, double min_norm,
+__device__ __forceinline__ T producer_scale(const double* part, int P, int stride, double numel, double min_norm,
                                             int r, bool* cond_out = nullptr) {
   if (part == nullptr) {
     if (cond_out) *cond_out = false;
     return (T)1;
   }
   const int lane = threadIdx.x & 63;
-  double v = lane < P ? part[(size_t)r * kMaxPartials + lane] : 0.0;
+  // lane l adds partials l, l + 64, ... (P <= 1024: at most 16 independent loads), then the xor butterfly: a fixed order
+  const double* __restrict__ pr = part + (size_t)r * stride;
+  double v = 0.0;
+  for (int i = lane; i < P; i += 64) v += pr[i];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   const T norm = (T)v;

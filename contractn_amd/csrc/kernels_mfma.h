@@ -258,8 +258,8 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 0] = __builtin_amdgcn_s_memtime();
 #endif
-  const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const float scA = producer_scale<float>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
+  const float scB = producer_scale<float>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
 
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
@@ -565,8 +565,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_reduce(StepArgs a, SplitKArgs sk) {
   __shared__ double red[4];
   const int r = blockIdx.y;
-  const T scA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const T scB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const T scA = producer_scale<T>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
+  const T scB = producer_scale<T>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
   const T iA = (T)1 / scA, iB = (T)1 / scB;
   T* __restrict__ C = (T*)a.ptrs[(size_t)r * a.n_tensors + a.idC];
   const T* __restrict__ slab = (const T*)sk.slab + (size_t)r * sk.S * sk.numelC;
@@ -715,8 +715,8 @@ __global__ __launch_bounds__(256, 2) void k_mfma_f64(StepArgs a) {
   const int m0 = (tt / a.tiles_n) * TM;
   const int n0 = (tt % a.tiles_n) * TN;
 
-  const double scA = producer_scale<double>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const double scB = producer_scale<double>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const double scA = producer_scale<double>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
+  const double scB = producer_scale<double>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const double* __restrict__ A = (const double*)tp[a.idA] + a.obA[b];
   const double* __restrict__ B = (const double*)tp[a.idB] + a.obB[b];

@@ -187,8 +187,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   // producers' abs-sum partials (reduced to the rescale factors after the main loop; index clamped,
   // lanes >= P masked there) and the C offset tables - 12 + (0..2) vector loads.
   double pva = 0.0, pvb = 0.0;
-  if (a.partA) pva = a.partA[(size_t)r * kMaxPartials + min(lane, a.PA - 1)];
-  if (a.partB) pvb = a.partB[(size_t)r * kMaxPartials + min(lane, a.PB - 1)];
+  // (lane l takes partials l, l + 64, ...: one load each for the usual <= 64 partials; the first index is clamped so
+  // that every lane requests something and the masking happens after the loop, where the values are used)
+  if (a.partA) {
+    const double* __restrict__ pr = a.partA + (size_t)r * a.strideA;
+    pva = pr[min(lane, a.PA - 1)];
+    for (int i = lane + 64; i < a.PA; i += 64) pva += pr[i];
+  }
+  if (a.partB) {
+    const double* __restrict__ pr = a.partB + (size_t)r * a.strideB;
+    pvb = pr[min(lane, a.PB - 1)];
+    for (int i = lane + 64; i < a.PB; i += 64) pvb += pr[i];
+  }
   int offm[4], offn[NJ][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) offm[i] = a.omC[m0 + wm + 32 * i + l31];

@@ -141,8 +141,18 @@ __global__ __launch_bounds__(256, (MA == 1 && MB == 1) ? 3 : 2) void k_mfma_f64_
   __builtin_amdgcn_sched_barrier(0);
   // epilogue operands, requested behind the first two k-tiles (see k_mfma_f32_g): 2 + 8 vector loads
   double pva = 0.0, pvb = 0.0;
-  if (a.partA) pva = a.partA[(size_t)r * kMaxPartials + min(lane, a.PA - 1)];
-  if (a.partB) pvb = a.partB[(size_t)r * kMaxPartials + min(lane, a.PB - 1)];
+  // (lane l takes partials l, l + 64, ...: one load each for the usual <= 64 partials; the first index is clamped so
+  // that every lane requests something and the masking happens after the loop, where the values are used)
+  if (a.partA) {
+    const double* __restrict__ pr = a.partA + (size_t)r * a.strideA;
+    pva = pr[min(lane, a.PA - 1)];
+    for (int i = lane + 64; i < a.PA; i += 64) pva += pr[i];
+  }
+  if (a.partB) {
+    const double* __restrict__ pr = a.partB + (size_t)r * a.strideB;
+    pvb = pr[min(lane, a.PB - 1)];
+    for (int i = lane + 64; i < a.PB; i += 64) pvb += pr[i];
+  }
   int offn[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) offn[j] = a.onC[n0 + wn + 16 * j + l15];

@@ -53,8 +53,8 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
   float* __restrict__ C = (float*)tp[a.idC] + a.obC[b];
 
   // everything that depends only on the step: requested first, consumed after the loop
-  const float scA = producer_scale<float>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const float scB = producer_scale<float>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const float scA = producer_scale<float>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
+  const float scB = producer_scale<float>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
   // rows / columns beyond M / N read padded table entries (in bounds) and are dropped at the store
   const int offA = a.omA[m0 + qm + l31], offB = a.onB[n0 + qn + l31];
   for (int k = tid; k < a.K; k += 512) { s_okA[k] = a.okA[k]; s_okB[k] = a.okB[k]; }
@@ -66,37 +66,46 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
   const int kbeg = ks * kchunk, kend = min(a.K, kbeg + kchunk);   // kchunk is even; a wave may own nothing
   const float* __restrict__ pa = A + offA;
   const float* __restrict__ pb = B + offB;
-  // Rounds of 8 k-steps, software-pipelined over two register sets: the 16 gathers of round r + 1 (their table
-  // look-ups are LDS reads) are all in flight while the 8 MFMAs of round r issue, so a round costs one L2 round
-  // trip OR its matrix-pipe time, whichever is longer - not their sum per load, which is what a compiler-chosen
-  // interleave of loads and MFMAs gave.
-  float xa0[8], xb0[8], xa1[8], xb1[8];
-  auto LOAD = [&](float (&ya)[8], float (&yb)[8], int k0) {
+  // Rounds of U k-steps, software-pipelined over two register sets: the 2U gathers of round r + 1 (their table
+  // look-ups are LDS reads) are all in flight while the U MFMAs of round r issue.  U = 32: a wave's share of a
+  // K = 1024 step (128 k) is two rounds, i.e. ALL its loads are requested before its first MFMA - one L2 round trip
+  // per step instead of one per round (with rounds of 8 the step took 22 us, dependent round trips back to back).
+  constexpr int U = 32;
+  float xa0[U], xb0[U], xa1[U], xb1[U];
+  auto LOAD = [&](float (&ya)[U], float (&yb)[U], int k0) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < U; ++u) {
       ya[u] = pa[s_okA[k0 + 2 * u + h]];
       yb[u] = pb[s_okB[k0 + 2 * u + h]];
     }
   };
-  auto MMA = [&](const float (&ya)[8], const float (&yb)[8]) {
+  auto MMA = [&](const float (&ya)[U], const float (&yb)[U]) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u], yb[u], acc, 0, 0, 0);
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u], yb[u], acc, 0, 0, 0);
   };
-  const int nround = kend > kbeg ? (kend - kbeg) / 16 : 0;
+  const int nround = kend > kbeg ? (kend - kbeg) / (2 * U) : 0;
   int rd = 0;
   if (nround > 0) LOAD(xa0, xb0, kbeg);
   for (; rd + 2 <= nround; rd += 2) {
-    LOAD(xa1, xb1, kbeg + 16 * (rd + 1));
+    LOAD(xa1, xb1, kbeg + 2 * U * (rd + 1));
     __builtin_amdgcn_sched_barrier(0);
     MMA(xa0, xb0);
     __builtin_amdgcn_sched_barrier(0);
-    if (rd + 2 < nround) LOAD(xa0, xb0, kbeg + 16 * (rd + 2));
+    if (rd + 2 < nround) LOAD(xa0, xb0, kbeg + 2 * U * (rd + 2));
     __builtin_amdgcn_sched_barrier(0);
     MMA(xa1, xb1);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (rd < nround) MMA(xa0, xb0);
-  int k = kbeg + 16 * nround;
+  int k = kbeg + 2 * U * nround;
+  // leftover of fewer than U k-steps: groups of 4 k-steps with their 8 gathers in flight together
+  for (; k + 8 <= kend; k += 8) {
+    float ya[4], yb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ya[u] = pa[s_okA[k + 2 * u + h]]; yb[u] = pb[s_okB[k + 2 * u + h]]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u], yb[u], acc, 0, 0, 0);
+  }
   for (; k < kend; k += 2) {                                       // tail: masked k (a zero pair adds nothing)
     const int kk = k + h;
     const bool in = kk < kend;

@@ -116,8 +116,8 @@ template <typename T, int V, int U>
 __global__ __launch_bounds__(256) void k_stream(StepArgs a) {
   __shared__ double red[4];
   const int r = blockIdx.y;
-  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const T sA = producer_scale<T>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const T* __restrict__ A = (const T*)tp[a.idA];
   const T* __restrict__ B = (const T*)tp[a.idB];
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void k_stream_kvec(StepArgs a) {
   typedef typename VecOf<T, V>::type VT;
   __shared__ double red[4];
   const int r = blockIdx.y;
-  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const T sA = producer_scale<T>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
   const bool da = sA != (T)1, db = sB != (T)1;
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const T* __restrict__ A = (const T*)tp[a.idA];
@@ -193,8 +193,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_rowdot(StepArgs a) {
   __shared__ double red[4];
   const int r = blockIdx.y;
-  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const T sA = producer_scale<T>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
   const bool divA = sA != (T)1, divB = sB != (T)1;
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const T* __restrict__ A = (const T*)tp[a.idA];
@@ -273,8 +273,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_dot(StepArgs a) {
   __shared__ double red[4];
   const int r = blockIdx.y;
-  const T sA = producer_scale<T>(a.partA, a.PA, a.numelA, a.min_norm, r);
-  const T sB = producer_scale<T>(a.partB, a.PB, a.numelB, a.min_norm, r);
+  const T sA = producer_scale<T>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const T* __restrict__ A = (const T*)tp[a.idA];
   const T* __restrict__ B = (const T*)tp[a.idB];
@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) void k_dot_split(StepArgs a, T* __restrict__ s
     slab[((size_t)r * S + s) * numelC + a.obC[b] + a.omC[m] + a.onC[n]] = tot;
 }
 
-// Collapse > 64 per-workgroup partials into one, in a fixed order.
+// Collapse more per-workgroup partials than a consumer wave adds (kMaxPartials) into one, in a fixed order;
+// the step's region then has a single slot per replica.
 __global__ __launch_bounds__(256) void k_collapse(const double* scratch, int blocks, double* part) {
   __shared__ double red[4];
   const int r = blockIdx.x;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void k_collapse(const double* scratch, int blo
   double v = 0;
   for (int i = threadIdx.x; i < blocks; i += 256) v += src[i];
   const double tot = block_sum(v, red);
-  if (threadIdx.x == 0) part[(size_t)r * kMaxPartials] = tot;
+  if (threadIdx.x == 0) part[r] = tot;
 }
 
 // ---------------------------------------------------------------------------
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void k_scales(FinalArgs f, double* __restrict_
   bool cond = false;
   T sc = (T)1;
   if (f.stabilize)
-    sc = producer_scale<T>(f.partials + (size_t)s * f.R * kMaxPartials, f.stepP[s], f.stepNumel[s],
+    sc = producer_scale<T>(f.partials + (size_t)f.stepOff[s] * f.R, f.stepP[s], f.stepSlots[s], f.stepNumel[s],
                            f.min_norm, r, &cond);
   if ((threadIdx.x & 63) == 0) {
     f.rescales[(size_t)r * f.n_steps + s] = cond ? (double)sc : 0.0;
@@ -391,10 +392,10 @@ __global__ __launch_bounds__(256) void k_finalize(FinalArgs f, const double* __r
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_renorm(void* const* __restrict__ ptrs, int n_tensors, int id, int64_t numel,
-                                                const double* __restrict__ part, int P, double min_norm) {
+                                                const double* __restrict__ part, int P, int stride, double min_norm) {
   const int r = blockIdx.y;
   bool cond = false;
-  const T sc = producer_scale<T>(part, P, (double)numel, min_norm, r, &cond);
+  const T sc = producer_scale<T>(part, P, stride, (double)numel, min_norm, r, &cond);
   if (!cond) return;
   T* __restrict__ x = (T*)ptrs[(size_t)r * n_tensors + id];
   constexpr int V = 16 / sizeof(T);
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void k_chain(const ChainStep* __restrict__ ste
     // the barriers inside block_sum also order this step's stores before the next step's loads
     const double tot = block_sum(absv, red);
     if (threadIdx.x == 0) {
-      partials[((size_t)s * R + r) * kMaxPartials] = tot;
+      partials[(size_t)s * R + r] = tot;   // chain plans: one slot per step and replica
       const T norm = (T)tot;
       sc[s] = (stabilize && norm > (T)min_norm) ? norm / (T)d.numelC : (T)1;
     }

@@ -339,7 +339,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
           round_up(st.N, 128) * 100 <= round_up(st.N, kTile64N) * 115 && st.rhs >= 0 &&
           P.tensors[st.lhs].numel <= (1LL << 29) && P.tensors[st.rhs].numel <= (1LL << 29))  // 32-bit byte offsets
         st.tileN = 128;
-    } else if (outs <= kMaxPartials && st.K >= 512) {
+    } else if (outs <= kWaveOutputs && st.K >= 512) {
       st.kernel = CTN_KERNEL_DOT;
       st.blocks = (int)outs;
     } else {

@@ -15,7 +15,9 @@
 
 namespace ctn {
 
-constexpr int kMaxPartials = 64;   // abs-sum partial slots per (step, replica): one wave reduces them
+constexpr int kMaxPartials = 1024;  // abs-sum partial slots per (step, replica) at most: one wave of the consumer adds them
+                                   // (16 per lane, fixed order); a step with more workgroups goes through k_collapse
+constexpr int kWaveOutputs = 64;   // "a handful of outputs": k_dot takes at most this many, the split-K reduce pass spreads over as many workgroups
 constexpr int kTileM = 128;        // MFMA f32 workgroup tile
 constexpr int kTileN = 128;
 constexpr int kTile64M = 128;      // MFMA f64 workgroup tile: 128 x 64

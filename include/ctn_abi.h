@@ -98,7 +98,7 @@ typedef struct {
   int64_t m, n, k;     /* |M|, |N| free extents, |K| contracted extent (incl. summed-out labels) */
   int32_t mode_a;      /* 0 gather, 1 vector loads along the free index, 2 vector loads along k */
   int32_t mode_b;
-  int32_t partials;    /* abs-sum partials per replica written by the step (<= 64) */
+  int32_t partials;    /* abs-sum partials per replica written by the step (<= 1024; more workgroups are collapsed to 1) */
   int32_t blocks;      /* workgroups per replica */
   double flops;        /* 2*|B||M||N||K| (|B||M||N| when K is empty) + 3*numel(out) */
   int64_t out_numel;

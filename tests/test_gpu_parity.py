@@ -342,12 +342,12 @@ def test_large_tile_dma_kernel_f64_vs_numpy(einstr, shapes, path, force_large_ti
 
 def test_launcher_retiles_by_replica_count():
     """The planner's tile is a default: the launcher takes 256 x 256 tiles for long-K full steps once there is
-    a tile per CU, and the latency kernel's 64 x 64 tiles for a single small network (ctn_exec_step_tile)."""
+    a tile per CU, and the one-launch latency form's 32 x 32 tiles for a single small network (ctn_exec_step_tile)."""
     rng = np.random.default_rng(23)
     A = (rng.standard_normal((1024, 256)) / 8).astype(np.float32)
     B = (rng.standard_normal((1024, 256)) / 8).astype(np.float32)
     ref = A.T.astype(np.float64) @ B.astype(np.float64)
-    for replicas, tile in ((1, (64, 64)), (256, (256, 256))):
+    for replicas, tile in ((1, (32, 32)), (256, (256, 256))):
         bc = E.BatchedContraction("km,kn->mn", [A.shape, B.shape], np.float32, optimize=((0, 1),), replicas=replicas)
         t, c = bc.run_host([[A, B]] * replicas)
         assert bc.executor.step_tiles() == [tile]
