@@ -146,12 +146,14 @@ __global__ __launch_bounds__(256, (MA == 1 && MB == 1) ? 3 : 2) void k_mfma_f64_
   if (a.partA) {
     const double* __restrict__ pr = a.partA + (size_t)r * a.strideA;
     pva = pr[min(lane, a.PA - 1)];
-    for (int i = lane + 64; i < a.PA; i += 64) pva += pr[i];
+    if (a.PA > 64)   // rare (a producer with more than 64 workgroups per replica): only this branch waits for the first load
+      for (int i = lane + 64; i < a.PA; i += 64) pva += pr[i];
   }
   if (a.partB) {
     const double* __restrict__ pr = a.partB + (size_t)r * a.strideB;
     pvb = pr[min(lane, a.PB - 1)];
-    for (int i = lane + 64; i < a.PB; i += 64) pvb += pr[i];
+    if (a.PB > 64)
+      for (int i = lane + 64; i < a.PB; i += 64) pvb += pr[i];
   }
   int offn[4];
 #pragma unroll

@@ -52,12 +52,37 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
   const float* __restrict__ B = (const float*)tp[a.idB] + a.obB[b];
   float* __restrict__ C = (float*)tp[a.idC] + a.obC[b];
 
-  // everything that depends only on the step: requested first, consumed after the loop
-  const float scA = producer_scale<float>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
-  const float scB = producer_scale<float>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
+  // ONE round trip for everything that does not depend on other loads - requested back to back, first used at the
+  // table copy below: the producers' abs-sum partials (reduced to the rescale factors after the loop, like
+  // k_mfma_f32_g), this lane's row / column offsets, the C offsets of the elements this thread will store, and the
+  // k-offset tables on their way to LDS.  (A kernel boundary leaves every load of a dependent step a ~1.5 us trip to
+  // the memory side; four such trips in a row - partials, tables, operands, C tables - made the step 14.7 us.)
+  constexpr int EPT = T * T / 512;                 // output elements per thread
+  double pva = 0.0, pvb = 0.0;
+  if (a.partA) {
+    const double* __restrict__ pr = a.partA + (size_t)r * a.strideA;
+    pva = pr[min(lane, a.PA - 1)];
+    if (a.PA > 64)   // rare (a producer with more than 64 workgroups per replica): only this branch waits for the first load
+      for (int i = lane + 64; i < a.PA; i += 64) pva += pr[i];
+  }
+  if (a.partB) {
+    const double* __restrict__ pr = a.partB + (size_t)r * a.strideB;
+    pvb = pr[min(lane, a.PB - 1)];
+    if (a.PB > 64)
+      for (int i = lane + 64; i < a.PB; i += 64) pvb += pr[i];
+  }
   // rows / columns beyond M / N read padded table entries (in bounds) and are dropped at the store
-  const int offA = a.omA[m0 + qm + l31], offB = a.onB[n0 + qn + l31];
+  int offA = a.omA[m0 + qm + l31], offB = a.onB[n0 + qn + l31];
+  int offc[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int idx = tid + 512 * i;
+    offc[i] = a.omC[m0 + idx / T] + a.onC[n0 + idx % T];
+  }
   for (int k = tid; k < a.K; k += 512) { s_okA[k] = a.okA[k]; s_okB[k] = a.okB[k]; }
+  asm volatile("" : "+v"(offA), "+v"(offB), "+v"(pva), "+v"(pvb));
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) asm volatile("" : "+v"(offc[i]));
   __syncthreads();
 
   f32x16 acc;
@@ -119,11 +144,19 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
   for (int e = 0; e < 16; ++e) s_part[w][((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] = acc[e];
   __syncthreads();
 
+  // the rescale factors from the partials requested at the start: exactly producer_scale<float>()
+  pva = lane < a.PA ? pva : 0.0;
+  pvb = lane < a.PB ? pvb : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { pva += __shfl_xor(pva, o, 64); pvb += __shfl_xor(pvb, o, 64); }
+  const float nA = (float)pva, nB = (float)pvb;
+  const float scA = (a.partA && nA > (float)a.min_norm) ? nA / (float)a.numelA : 1.f;
+  const float scB = (a.partB && nB > (float)a.min_norm) ? nB / (float)a.numelB : 1.f;
   // every thread finishes T*T/512 elements: the KS partials of its quadrant in wave order, lazy rescale, store
   const float iA = 1.0f / scA, iB = 1.0f / scB;
   float asum = 0.f;
 #pragma unroll
-  for (int i = 0; i < T * T / 512; ++i) {
+  for (int i = 0; i < EPT; ++i) {
     const int idx = tid + 512 * i;                 // element of the tile, column fastest
     const int row = idx / T, col = idx % T;
     const int qq = (row / 32) * Q + (col / 32);
@@ -133,7 +166,7 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
     for (int s = 1; s < KS; ++s) v += s_part[qq + s * Q * Q][off];
     v = (v * iA) * iB;
     if (m0 + row < a.M && n0 + col < a.N) {
-      C[a.omC[m0 + row] + a.onC[n0 + col]] = v;
+      C[offc[i]] = v;
       asum += fabsf(v);
     }
   }
