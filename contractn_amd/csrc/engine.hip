@@ -222,17 +222,22 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSw
 }
 
 // One-launch latency form (k_mfma_f32_lat): K split over the eight waves of a workgroup instead of over
-// workgroups, no slabs and no reduce launch.  Returns the tile form Q (1: 32 x 32 tiles, 2: 64 x 64), 0 = not taken.
-// Same launch-size condition as split-K (the step's 128-wide tiles cannot occupy half the chip), at most 64 tiles
-// per replica (one abs-sum partial each), both k-offset tables in LDS, at most 256 MFMAs per wave.
+// workgroups, no slabs and no reduce launch.  Returns the tile edge T (16, 32 or 64), 0 = not taken.
+// Same launch-size condition as split-K (the step's 128-wide tiles cannot occupy half the chip); the largest tile
+// that still gives every CU a workgroup (with one network in flight a 256 x 256 x 1024 step runs as 256 tiles of
+// 16 x 16: on 64 tiles of 32 x 32 three quarters of the matrix pipes idle and the step takes 14 us instead of ~6);
+// at most kMaxPartials tiles per replica (one abs-sum partial each), both k-offset tables in LDS.
 static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
   if (sw.lat == 0 || dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.rhs < 0) return 0;
   if (st.K > kLatMaxK || st.K < 32) return 0;
   if (sw.lat != 1 && ((int64_t)st.blocks * R > n_cu / 2 || st.K < 128)) return 0;
-  const int64_t t32 = st.Bt * ((st.M + 31) / 32) * ((st.N + 31) / 32);
-  const int64_t t64 = st.Bt * ((st.M + 63) / 64) * ((st.N + 63) / 64);
-  if (t32 <= kWaveOutputs && st.K <= 8 * 512) return 1;
-  if (t64 <= kWaveOutputs && st.K <= 2 * 512) return 2;
+  auto tiles = [&](int T) { return st.Bt * ((st.M + T - 1) / T) * ((st.N + T - 1) / T); };
+  const int64_t t16 = tiles(16), t32 = tiles(32), t64 = tiles(64);
+  if (t64 * R >= n_cu && t64 <= kMaxPartials && st.K <= 2 * 512) return 64;
+  if (t32 * R >= n_cu && t32 <= kMaxPartials) return 32;
+  if (t16 <= kMaxPartials) return 16;
+  if (t32 <= kMaxPartials) return 32;
+  if (t64 <= kMaxPartials && st.K <= 2 * 512) return 64;
   return 0;
 }
 
@@ -388,18 +393,18 @@ static int exec_launch_steps(Exec* E) {
       case CTN_KERNEL_MFMA_F32: {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
-        if (const int Q = lat_form(st, R, E->n_cu, P.dtype, E->sw)) {
-          const int T = 32 * Q;
+        if (const int T = lat_form(st, R, E->n_cu, P.dtype, E->sw)) {
           a.tiles_m = (int32_t)((st.M + T - 1) / T);
           a.tiles_n = (int32_t)((st.N + T - 1) / T);
           a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
           a.partC = part_dst; a.partC_stride = part_stride; reduced = true;   // one partial per tile, written directly
-          const int ks = Q == 1 ? 8 : 2;
-          const int kchunk = (int)(((st.K + ks - 1) / ks + 1) / 2 * 2);
+          const int ks = T == 64 ? 2 : 8, kp = T == 16 ? 4 : 2;
+          const int kchunk = (int)(((st.K + ks - 1) / ks + kp - 1) / kp * kp);
           used_tile(T, T);
           const dim3 g((unsigned)((int64_t)a.blocks_per_replica * R));
-          if (Q == 1) hipLaunchKernelGGL(k_mfma_f32_lat<1>, g, dim3(512), 0, E->stream, a, kchunk);
-          else hipLaunchKernelGGL(k_mfma_f32_lat<2>, g, dim3(512), 0, E->stream, a, kchunk);
+          if (T == 16) hipLaunchKernelGGL(k_mfma_f32_lat<16>, g, dim3(512), 0, E->stream, a, kchunk);
+          else if (T == 32) hipLaunchKernelGGL(k_mfma_f32_lat<32>, g, dim3(512), 0, E->stream, a, kchunk);
+          else hipLaunchKernelGGL(k_mfma_f32_lat<64>, g, dim3(512), 0, E->stream, a, kchunk);
           break;
         }
         if (const int S = E->d_slab ? splitk_splits(st, R, E->n_cu, P.dtype, E->sw) : 0) {
@@ -896,8 +901,8 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   for (int s = 0; s < P.n_steps; ++s) {
     const Step& st = P.steps[s];
     E.step_partials[s] = std::max(st.partials, 1);
-    if (const int Q = lat_form(st, replicas, E.n_cu, P.dtype, E.sw))
-      E.step_partials[s] = (int)(st.Bt * ((st.M + 32 * Q - 1) / (32 * Q)) * ((st.N + 32 * Q - 1) / (32 * Q)));
+    if (const int T = lat_form(st, replicas, E.n_cu, P.dtype, E.sw))
+      E.step_partials[s] = (int)(st.Bt * ((st.M + T - 1) / T) * ((st.N + T - 1) / T));
     else if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
                           rowdot_splits(st, replicas, E.n_cu)))
       E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kWaveOutputs, P.tensors[st.out].numel / 1024));

@@ -342,12 +342,12 @@ def test_large_tile_dma_kernel_f64_vs_numpy(einstr, shapes, path, force_large_ti
 
 def test_launcher_retiles_by_replica_count():
     """The planner's tile is a default: the launcher takes 256 x 256 tiles for long-K full steps once there is
-    a tile per CU, and the one-launch latency form's 32 x 32 tiles for a single small network (ctn_exec_step_tile)."""
+    a tile per CU, and the one-launch latency form's 16 x 16 tiles for a single small network (ctn_exec_step_tile)."""
     rng = np.random.default_rng(23)
     A = (rng.standard_normal((1024, 256)) / 8).astype(np.float32)
     B = (rng.standard_normal((1024, 256)) / 8).astype(np.float32)
     ref = A.T.astype(np.float64) @ B.astype(np.float64)
-    for replicas, tile in ((1, (32, 32)), (256, (256, 256))):
+    for replicas, tile in ((1, (16, 16)), (256, (256, 256))):
         bc = E.BatchedContraction("km,kn->mn", [A.shape, B.shape], np.float32, optimize=((0, 1),), replicas=replicas)
         t, c = bc.run_host([[A, B]] * replicas)
         assert bc.executor.step_tiles() == [tile]
@@ -390,32 +390,37 @@ def test_latency_mode_split_k(dtype, tol, einstr, shapes, monkeypatch):
     E.clear_caches()
 
 
-@pytest.mark.parametrize("einstr,shapes,tile", [
-    ("mk,kn->mn", [(256, 1024), (1024, 256)], (32, 32)),      # the MPS environment step: 64 tiles, 128 k per wave
-    ("km,kn->mn", [(256, 256), (256, 1024)], (64, 64)),       # the other zipper step: 64 tiles of 64 x 64, two K halves
-    ("km,kn->mn", [(300, 70), (300, 100)], (32, 32)),         # ragged M, N and K (k chunks of 38: tail rounds)
-    ("mk,nk->mn", [(130, 200), (90, 200)], (32, 32)),         # both k-contiguous, ragged tiles
-    ("xkm,xkn->xmn", [(2, 160, 64), (2, 160, 96)], (32, 32)),  # batch label: 2 x 2 x 3 tiles
-    ("kam,kbn->ambn", [(136, 4, 24), (136, 2, 40)], (32, 32)),  # composite free indices, strided C
-    ("km,kn->mn", [(4096, 64), (4096, 64)], (32, 32)),        # K = 4096: both tables fill their LDS arrays
-    ("km,kn->mn", [(130, 512), (130, 400)], (64, 64)),        # 8 x 7 tiles of 64: odd k chunk (65 -> 66)
+@pytest.mark.parametrize("einstr,shapes,replicas,tile", [
+    ("mk,kn->mn", [(256, 1024), (1024, 256)], 1, (16, 16)),    # the MPS environment step alone: 256 tiles of 16 x 16 fill the chip
+    ("mk,kn->mn", [(256, 1024), (1024, 256)], 4, (32, 32)),    # ... four networks in flight: 4 x 64 tiles of 32 x 32
+    ("km,kn->mn", [(256, 256), (256, 1024)], 1, (32, 32)),     # the other zipper step: 256 tiles of 32 x 32
+    ("km,kn->mn", [(256, 256), (256, 1024)], 4, (64, 64)),     # ... 4 x 64 tiles of 64 x 64, two K halves per block
+    ("km,kn->mn", [(300, 70), (300, 100)], 1, (16, 16)),       # ragged M, N and K (k chunks of 40: leftover groups + tail)
+    ("mk,nk->mn", [(130, 200), (90, 200)], 2, (16, 16)),       # both k-contiguous, ragged tiles
+    ("xkm,xkn->xmn", [(2, 160, 64), (2, 160, 96)], 1, (16, 16)),  # batch label: 2 x 4 x 6 tiles
+    ("kam,kbn->ambn", [(136, 4, 24), (136, 2, 40)], 1, (16, 16)),  # composite free indices, strided C
+    ("km,kn->mn", [(4096, 64), (4096, 64)], 1, (16, 16)),      # K = 4096: both tables fill their LDS arrays
+    ("km,kn->mn", [(130, 512), (130, 400)], 3, (32, 32)),      # 3 x 208 tiles of 32: odd k chunk (17 -> 18)
+    ("km,kn->mn", [(130, 512), (130, 448)], 5, (64, 64)),      # 5 x 56 tiles of 64: k chunk 65 -> 66
 ])
-def test_latency_mode_one_launch(einstr, shapes, tile):
-    """One network in flight, fp32: the step runs as ONE launch of k_mfma_f32_lat - K split over the eight waves of
-    a workgroup, partials added in wave order in LDS - instead of split-K slabs plus a reduce launch."""
+def test_latency_mode_one_launch(einstr, shapes, replicas, tile):
+    """A few networks in flight, fp32: the step runs as ONE launch of k_mfma_f32_lat - K split over the eight waves
+    of a workgroup, partials added in wave order in LDS, the tile (16 / 32 / 64) the largest that still gives every
+    CU a workgroup - instead of split-K slabs plus a reduce launch."""
     rng = np.random.default_rng(6)
-    ops = [rng.standard_normal(s).astype(np.float32) for s in shapes]
-    bc = E.BatchedContraction(einstr, shapes, np.float32, optimize=((0, 1),), replicas=1)
-    t, c = bc.run_host([ops])
+    sets = [[rng.standard_normal(s).astype(np.float32) for s in shapes] for _ in range(replicas)]
+    bc = E.BatchedContraction(einstr, shapes, np.float32, optimize=((0, 1),), replicas=replicas)
+    t, c = bc.run_host(sets)
     assert bc.executor.step_tiles() == [tile]
-    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
-    got = t[0].astype(np.float64) * np.exp(float(c[0]))
-    assert np.max(np.abs(got - ref)) <= 2e-4 * np.max(np.abs(ref))
-    assert abs(np.mean(np.abs(t[0])) - 1.0) < 1e-5
-    t2, c2 = bc.run_host([ops])                              # fixed reduction order: the same bits every time
+    for r in range(replicas):
+        ref = np.einsum(einstr, *[o.astype(np.float64) for o in sets[r]])
+        got = t[r].astype(np.float64) * np.exp(float(c[r]))
+        assert np.max(np.abs(got - ref)) <= 2e-4 * np.max(np.abs(ref))
+        assert abs(np.mean(np.abs(t[r])) - 1.0) < 1e-5
+    t2, c2 = bc.run_host(sets)                               # fixed reduction order: the same bits every time
     assert np.array_equal(t2, t) and np.array_equal(c2, c)
     bc.executor.close()
-    # small exact integers: every product and partial sum is exact, so the result is NumPy's bit for bit
+    # small exact integers: every product and partial sum is exact, so the result is NumPy's
     iops = [rng.integers(-3, 4, size=s).astype(np.float32) for s in shapes]
     ti, ci = contract(einstr, *iops, split_format=True)
     refi = np.einsum(einstr, *[o.astype(np.float64) for o in iops])
@@ -431,7 +436,7 @@ def test_latency_mode_feeds_rescaled_intermediates(monkeypatch):
     plan, ex = _plan_and_executor(g)
     outs, _log, resc = ex.run_host([g["operands"]])
     tiles = ex.step_tiles()
-    assert sum(t == (32, 32) for t in tiles) >= 6, tiles
+    assert sum(t in ((16, 16), (32, 32)) for t in tiles) >= 6, tiles
     c = E.accumulate_log_scale(resc[0], np.dtype(np.float32))
     assert float(outs[0]) == float(g["t_hat"]) and abs(float(c) - float(g["log_scale"])) <= 2e-5 * abs(float(g["log_scale"]))
     E.clear_caches()
