@@ -45,7 +45,7 @@ thread_local std::string g_err;
 struct DevSwitches {
   int mfma_g = 1;        // CTN_MFMA_G: 0 never use the large-tile LDS-DMA kernels, 1 when a launch fills the chip, 2 whenever eligible (tests)
   int graph = 1;         // CTN_GRAPH=0: every enqueue issues its launches one by one
-  int mfma_bk = 0;       // CTN_MFMA_BK=16|32|64: force the k-tile depth of k_mfma_f32 (64 = single shot, K <= 64 only)
+  int mfma_bk = 0;       // CTN_MFMA_BK=16|32: force the k-tile depth of k_mfma_f32
   int splitk = -1;       // CTN_SPLITK: 0 disables the latency mode, 1 forces it for every eligible step (tests)
   int splitk_max = 0;    // CTN_SPLITK_MAX: tile-count threshold of the latency mode
   int lanes = 8;         // CTN_LANES: side streams for independent branches of the tree inside the captured graph (0 = none)
@@ -60,7 +60,7 @@ static DevSwitches read_dev_switches() {
   d.mfma_g = num("CTN_MFMA_G", 1);
   d.graph = num("CTN_GRAPH", 1);
   const int bk = num("CTN_MFMA_BK", 0);
-  d.mfma_bk = (bk == 16 || bk == 32 || bk == 64) ? bk : 0;
+  d.mfma_bk = (bk == 16 || bk == 32) ? bk : 0;
   d.splitk = num("CTN_SPLITK", -1);
   d.splitk_max = num("CTN_SPLITK_MAX", 0);
   d.lat = num("CTN_LAT", -1);
@@ -202,25 +202,13 @@ static void launch_mfma_a(int ma, int mb, dim3 grid, hipStream_t st, const StepA
 // (4096^3: 130 vs 115 TFLOP/s).  CTN_MFMA_BK=16|32 forces one of them (development knob).
 static int mfma_bk(int K, const DevSwitches& sw) {
   if (sw.mfma_bk) return sw.mfma_bk;
-  if (K > 32 && K <= 64) return 64;      // single shot: the whole (short) K at once
   return K >= 2048 ? 32 : 16;
 }
 
 // tile_m = 64: skinny rows (M <= 64 against a huge N) - always BK = 16 (these steps have a short K)
 static void launch_mfma(int ma, int mb, int tile_m, int tile_n, dim3 grid, hipStream_t st, const StepArgs& a, const DevSwitches& sw) {
-  const int bk = mfma_bk(a.K, sw);
-  const bool bk16 = bk != 32;
-  // (a forced CTN_MFMA_BK=64 only applies where the single buffer suffices; an operand that is gathered element by
-  // element along a 128-wide tile edge would stage 32 scalars per thread and spill: those keep the 16-deep loop)
-  if (bk == 64 && a.K <= 64 && !(tile_n == 128 && mb == 0) && !(tile_m == 128 && ma == 0)) {
-    if (tile_m == 64) {
-      if (tile_n == 64) launch_mfma_a<64, 64, 64>(ma, mb, grid, st, a);
-      else launch_mfma_a<64, 128, 64>(ma, mb, grid, st, a);
-    } else {
-      if (tile_n == 64) launch_mfma_a<64, 64, 128>(ma, mb, grid, st, a);
-      else launch_mfma_a<64, 128, 128>(ma, mb, grid, st, a);
-    }
-  } else if (tile_m == 64) {
+  const bool bk16 = mfma_bk(a.K, sw) == 16;
+  if (tile_m == 64) {
     if (tile_n == 64) launch_mfma_a<16, 64, 64>(ma, mb, grid, st, a);
     else launch_mfma_a<16, 128, 64>(ma, mb, grid, st, a);
   } else if (tile_n == 64) {

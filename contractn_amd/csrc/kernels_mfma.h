@@ -224,7 +224,7 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLo
 // second launch-bound argument = waves per SIMD the register allocator must leave room for:
 // BK = 16 is sized for 3 workgroups per CU (<= 168 registers), BK = 32 for 2
 template <int MA, int MB, int BK, int TN, int BM = kTileM>
-__global__ __launch_bounds__(256, (BK == 16 || (BK == 64 && BM == 64) ? 3 : 2)) void k_mfma_f32(StepArgs a) {
+__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a) {
   static_assert((BM == 128 || BM == 64) && (TN == 128 || TN == 64), "tile shapes");
   using LA = TileLoader<MA, BK, BM>;
   using LB = TileLoader<MB, BK, TN>;
@@ -233,15 +233,10 @@ __global__ __launch_bounds__(256, (BK == 16 || (BK == 64 && BM == 64) ? 3 : 2)) 
   constexpr int NI = BM / 64;
   // one LDS object: [A buf0][A buf1][B buf0][B buf1][omC BM][onC TN][red 4 doubles]; the operand buffers double as
   // the epilogue's per-wave staging area (32 rows x TN/2 columns each), which for the 64-row tile is the larger of the two
-  // BK = 64 is the single-shot form for short-K steps (K <= 64: PEPS absorptions, 16 flop/B): the whole K extent
-  // of both operand tiles is requested at once - 48-64 KB in flight per workgroup, two or three workgroups per CU -
-  // into ONE buffer, multiplied, stored; no k loop, no double buffer.  At the HBM ridge what counts is bytes in
-  // flight, and a 4-deep loop of 16-wide k-tiles with a barrier each keeps only a quarter of them there.
-  constexpr int NB = BK >= 64 ? 1 : 2;
-  constexpr int BUF = (NB * SZA + NB * SZB > 4 * 32 * (TN / 2) ? NB * SZA + NB * SZB : 4 * 32 * (TN / 2) + 3) & ~3;
+  constexpr int BUF = (2 * SZA + 2 * SZB > 4 * 32 * (TN / 2) ? 2 * SZA + 2 * SZB : 4 * 32 * (TN / 2) + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float smem[BUF + BM + TN + 8];
   float* sA = smem;
-  float* sB = smem + NB * SZA;
+  float* sB = smem + 2 * SZA;
   int* s_omC = reinterpret_cast<int*>(smem + BUF);
   int* s_onC = s_omC + BM;
   double* red = reinterpret_cast<double*>(s_onC + TN);
