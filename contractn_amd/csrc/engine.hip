@@ -363,17 +363,13 @@ static int exec_launch_steps(Exec* E) {
     hipStream_t strm = E->stream;
     if (lanes) {
       const int ln = E->lane[s];
-      if (getenv("CTN_DEBUG_LANES")) {
-        fprintf(stderr, "[lanes] step %d lane %d deps:", s, ln);
-        for (int dsp : E->deps[s]) fprintf(stderr, " %d(l%d,e%d)", dsp, E->lane[dsp], (int)E->needs_event[dsp]);
-        fprintf(stderr, "\n");
-      }
       strm = ln == 0 ? E->stream : E->side[ln - 1];
       if (ln != 0 && !E->lane_joined[ln]) {          // a side stream joins the capture by waiting for the fork event
         HIPCHECK(hipStreamWaitEvent(strm, E->ev_fork, 0));
         E->lane_joined[ln] = true;
       }
-      for (int dsp : E->deps[s]) HIPCHECK(hipStreamWaitEvent(strm, E->ev_done[dsp], 0));
+      for (int dsp : E->deps[s])
+        if (E->lane[dsp] != ln) HIPCHECK(hipStreamWaitEvent(strm, E->ev_done[dsp], 0));
     }
     StepArgs a;
     const int32_t* T = E->d_tables;
@@ -736,17 +732,13 @@ static int exec_launch_all(Exec* E) {
       return exec_launch_steps(E);
     }
     E->capturing_lanes = !E->side.empty();
-    const bool dbg = getenv("CTN_DEBUG_LANES") != nullptr;
-    if (dbg) fprintf(stderr, "[lanes] capture begins: %zu side streams, %d steps\n", E->side.size(), P.n_steps);
     if (E->capturing_lanes) {
       std::fill(E->lane_joined.begin(), E->lane_joined.end(), 0);
       if (hipEventRecord(E->ev_fork, E->stream) != hipSuccess) { (void)hipGetLastError(); E->capturing_lanes = false; }
     }
     const int rc = exec_launch_steps(E);
     E->capturing_lanes = false;
-    if (dbg) fprintf(stderr, "[lanes] steps captured rc=%d\n", rc);
     const hipError_t ec = hipStreamEndCapture(E->stream, &g);
-    if (dbg) fprintf(stderr, "[lanes] end capture: %s\n", hipGetErrorString(ec));
     if (rc != CTN_OK || ec != hipSuccess || !g ||
         hipGraphInstantiate(&E->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
       (void)hipGetLastError();
@@ -757,7 +749,6 @@ static int exec_launch_all(Exec* E) {
     }
     (void)hipGraphDestroy(g);
     E->graph_aligned = E->outs_aligned16;
-    if (dbg) fprintf(stderr, "[lanes] graph instantiated\n");
   }
   HIPCHECK(hipGraphLaunch(E->graph_exec, E->stream));
   return CTN_OK;
@@ -971,7 +962,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   // ---- DAG lanes for the captured graph (CTN_LANES side streams; see exec_launch_steps) ---------------------
   // A step continues the lane of an operand's producer when that producer is still the lane's tail (no event
   // needed), else - a step on inputs only, or one whose producers' lanes have moved on - it opens the least
-  // recently used side lane; a step that joins two side lanes goes to the main stream (see below).  Steps that use the executor-wide scratch (collapse partials, split-K slabs) stay on
+  // recently used side lane.  Steps that use the executor-wide scratch (collapse partials, split-K slabs) stay on
   // the main stream, which orders them among themselves.
   if (E.sw.lanes > 0 && E.use_graph && !P.chain && P.n_steps >= 8) {
     const int NL = E.sw.lanes + 1;
@@ -1007,43 +998,14 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
         for (int l = 1; l < NL; ++l)
           if (last_use[l] < last_use[ln]) ln = l;
       }
-      // this ROCm's hipStreamEndCapture dies on a side stream that waits for ANOTHER side stream's event
-      // (tools/capture_lanes_probe.hip: fork/join through the origin stream is fine, side <-> side is not): a step
-      // with a dependency on a different side lane therefore runs on the main stream, which may wait for anybody
-      if (ln != 0)
-        for (int d : E.deps[s])
-          if (E.lane[d] != 0 && E.lane[d] != ln) { ln = 0; break; }
       E.lane[s] = ln;
       E.lane_tail[ln] = s;
       last_use[ln] = s;
       if (ln > 0) side_lanes_used = std::max(side_lanes_used, ln);
     }
-    // Which events a step really has to wait for: per lane a vector clock (for every other lane the latest step of it
-    // that this lane is already ordered behind, directly or through somebody it waited for).  Only dependencies that
-    // are ahead of the clock become waits - at most one per other lane and step - so the captured graph carries a
-    // minimal set of cross-stream edges.
-    {
-      std::vector<std::vector<int>> clock(NL, std::vector<int>(NL, -1));     // clock[lane][other lane]
-      std::vector<std::vector<int>> at_step(P.n_steps);                       // the lane's clock right after a step
-      std::vector<std::vector<int>> waits(P.n_steps);
-      for (int s = 0; s < P.n_steps; ++s) {
-        const int ln = E.lane[s];
-        std::vector<int> need(NL, -1);
-        for (int d : E.deps[s])
-          if (E.lane[d] != ln) need[E.lane[d]] = std::max(need[E.lane[d]], d);
-        for (int o = 0; o < NL; ++o)
-          if (need[o] > clock[ln][o]) {
-            waits[s].push_back(need[o]);
-            for (int q = 0; q < NL; ++q) clock[ln][q] = std::max(clock[ln][q], at_step[need[o]][q]);
-            clock[ln][o] = std::max(clock[ln][o], need[o]);
-          }
-        clock[ln][ln] = s;
-        at_step[s] = clock[ln];
-      }
-      E.deps.swap(waits);                      // from here on deps[s] = the events step s waits for
-      for (int s = 0; s < P.n_steps; ++s)
-        for (int d : E.deps[s]) E.needs_event[d] = 1;
-    }
+    for (int s = 0; s < P.n_steps; ++s)
+      for (int d : E.deps[s])
+        if (E.lane[d] != E.lane[s]) E.needs_event[d] = 1;
     for (int l = 1; l < NL; ++l)
       if (E.lane_tail[l] >= 0) E.needs_event[E.lane_tail[l]] = 1;
     if (side_lanes_used > 0) {
