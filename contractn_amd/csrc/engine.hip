@@ -48,7 +48,6 @@ struct DevSwitches {
   int mfma_bk = 0;       // CTN_MFMA_BK=16|32: force the k-tile depth of k_mfma_f32
   int splitk = -1;       // CTN_SPLITK: 0 disables the latency mode, 1 forces it for every eligible step (tests)
   int splitk_max = 0;    // CTN_SPLITK_MAX: tile-count threshold of the latency mode
-  int lanes = 8;         // CTN_LANES: side streams for independent branches of the tree inside the captured graph (0 = none)
   int lat = -1;          // CTN_LAT: 0 never use the one-launch latency form (k_mfma_f32_lat), 1 whenever the shape allows (tests)
   bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
   const char* stamps = nullptr;  // CTN_DEBUG_STAMPS=<file> (make STAMPS=1 builds): dump in-kernel cycle stamps
@@ -64,7 +63,6 @@ static DevSwitches read_dev_switches() {
   d.splitk = num("CTN_SPLITK", -1);
   d.splitk_max = num("CTN_SPLITK_MAX", 0);
   d.lat = num("CTN_LAT", -1);
-  d.lanes = std::max(0, std::min(16, num("CTN_LANES", 8)));
   d.g_no_asm = getenv("CTN_G_NO_ASM") != nullptr;
   d.stamps = getenv("CTN_DEBUG_STAMPS");
   d.stamp_step = num("CTN_DEBUG_STAMP_STEP", -1);
@@ -147,16 +145,6 @@ struct Exec {
   bool eager_forced = false;        // ctn_exec_set_rescale_mode(1)
   int eager_reruns = 0;
   std::vector<double> h_resc;       // host copy of the last run's per-step rescale factors [R][n_steps]
-  // DAG lanes (graph capture only, see exec_launch_steps)
-  std::vector<hipStream_t> side;    // side streams (lanes 1..)
-  std::vector<int> lane;            // per step: 0 = main stream
-  std::vector<std::vector<int>> deps;   // per step: steps it must wait for (operand producers + workspace re-use)
-  std::vector<char> needs_event;    // per step: somebody on another lane waits for it (or it ends a side lane)
-  std::vector<int> lane_tail;       // per lane: last step on it (-1 none)
-  std::vector<char> lane_joined;    // per lane, during a capture: has joined
-  std::vector<hipEvent_t> ev_done;  // per step (only those with needs_event are created)
-  hipEvent_t ev_fork = nullptr;
-  bool capturing_lanes = false;
   int timing_slots = 0;             // 0 = timing off
   int timing_runs = 0;              // enqueues recorded since timing was enabled
   std::vector<hipEvent_t> events;   // [slot][step][2]
@@ -170,9 +158,6 @@ struct Exec {
       if (p) (void)hipFree(p);
     if (h_pack) (void)hipHostFree(h_pack);
     for (auto ev : events) (void)hipEventDestroy(ev);
-    for (auto ev : ev_done) if (ev) (void)hipEventDestroy(ev);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    for (auto st_ : side) if (st_) (void)hipStreamDestroy(st_);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -259,7 +244,7 @@ static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitche
 // the reduce pass of a split-K step: fold 16 to 1 while more than 16 slabs are left (ping-pong between the two
 // slab buffers), then the final pass (rescale, C, abs-sum partials)
 template <typename T>
-static void launch_splitk_reduce(Exec* E, hipStream_t S, int partials, int R, const StepArgs& a, SplitKArgs sk);
+static void launch_splitk_reduce(Exec* E, int partials, int R, const StepArgs& a, SplitKArgs sk);
 
 // A streaming step with few output items and a long K (column sums, `ab,ab->b`: 4 workgroups walked K = 4096 one
 // element at a time - 1.7 ms for 67 MB): split K over workgroups, partial sums through the split-K reduce pass
@@ -319,20 +304,20 @@ static void launch_sk64(int ma, int mb, dim3 grid, hipStream_t st, const StepArg
 }
 
 template <typename T>
-static void launch_splitk_reduce(Exec* E, hipStream_t S, int partials, int R, const StepArgs& a, SplitKArgs sk) {
+static void launch_splitk_reduce(Exec* E, int partials, int R, const StepArgs& a, SplitKArgs sk) {
   T* bufs[2] = {(T*)E->d_slab, (T*)E->d_slab2};
   int cur = 0;
   while (sk.S > 16 && E->d_slab2) {
     const int S_out = (sk.S + 15) / 16;
     constexpr int V = 16 / sizeof(T);
     const dim3 grid((unsigned)((sk.numelC + 256 * V - 1) / (256 * V)), (unsigned)S_out, (unsigned)R);
-    hipLaunchKernelGGL(k_splitk_fold<T>, grid, dim3(256), 0, S, (const T*)bufs[cur], bufs[cur ^ 1],
+    hipLaunchKernelGGL(k_splitk_fold<T>, grid, dim3(256), 0, E->stream, (const T*)bufs[cur], bufs[cur ^ 1],
                        sk.numelC, sk.S, S_out);
     cur ^= 1;
     sk.S = S_out;
   }
   sk.slab = bufs[cur];
-  hipLaunchKernelGGL(k_splitk_reduce<T>, dim3(partials, R), dim3(256), 0, S, a, sk);
+  hipLaunchKernelGGL(k_splitk_reduce<T>, dim3(partials, R), dim3(256), 0, E->stream, a, sk);
 }
 
 static int exec_launch_steps(Exec* E) {
@@ -353,24 +338,8 @@ static int exec_launch_steps(Exec* E) {
                          (void* const*)E->d_ptrs, E->n_tensors, E->d_partials, R, P.min_norm, P.stabilize ? 1 : 0);
     if (timed) HIPCHECK(hipEventRecord(E->events[ev0 + 1], E->stream));  // whole walk = "step 0"
   }
-  // Lanes: while the launch sequence is being captured into a hipGraph, a step runs on the stream of its lane
-  // (E->lane, assigned when the executor was created) and waits for exactly the steps it depends on - its operands'
-  // producers and the last readers of the workspace region its output re-uses - so independent branches of the
-  // contraction tree become parallel branches of the graph.  Outside a capture everything runs on E->stream.
-  const bool lanes = E->capturing_lanes;
   for (int s = 0; s < P.n_steps && !chain; ++s) {
     const Step& st = P.steps[s];
-    hipStream_t strm = E->stream;
-    if (lanes) {
-      const int ln = E->lane[s];
-      strm = ln == 0 ? E->stream : E->side[ln - 1];
-      if (ln != 0 && !E->lane_joined[ln]) {          // a side stream joins the capture by waiting for the fork event
-        HIPCHECK(hipStreamWaitEvent(strm, E->ev_fork, 0));
-        E->lane_joined[ln] = true;
-      }
-      for (int dsp : E->deps[s])
-        if (E->lane[dsp] != ln) HIPCHECK(hipStreamWaitEvent(strm, E->ev_done[dsp], 0));
-    }
     StepArgs a;
     const int32_t* T = E->d_tables;
     a.obA = T + st.t.obA; a.obB = T + st.t.obB; a.obC = T + st.t.obC;
@@ -417,7 +386,7 @@ static int exec_launch_steps(Exec* E) {
 
     const bool timed = E->timing_runs < E->timing_slots;  // only the first `slots` enqueues are bracketed
     const size_t ev0 = timed ? ((size_t)E->timing_runs * P.n_steps + s) * 2 : 0;
-    if (timed) HIPCHECK(hipEventRecord(E->events[ev0], strm));
+    if (timed) HIPCHECK(hipEventRecord(E->events[ev0], E->stream));
     if ((int)E->launched_tile.size() != P.n_steps) E->launched_tile.assign(P.n_steps, 0);
     auto used_tile = [&](int tm, int tn) { E->launched_tile[s] = (tm << 16) | tn; };
     switch (st.kernel) {
@@ -433,9 +402,9 @@ static int exec_launch_steps(Exec* E) {
           const int kchunk = (int)(((st.K + ks - 1) / ks + kp - 1) / kp * kp);
           used_tile(T, T);
           const dim3 g((unsigned)((int64_t)a.blocks_per_replica * R));
-          if (T == 16) hipLaunchKernelGGL(k_mfma_f32_lat<16>, g, dim3(512), 0, strm, a, kchunk);
-          else if (T == 32) hipLaunchKernelGGL(k_mfma_f32_lat<32>, g, dim3(512), 0, strm, a, kchunk);
-          else hipLaunchKernelGGL(k_mfma_f32_lat<64>, g, dim3(512), 0, strm, a, kchunk);
+          if (T == 16) hipLaunchKernelGGL(k_mfma_f32_lat<16>, g, dim3(512), 0, E->stream, a, kchunk);
+          else if (T == 32) hipLaunchKernelGGL(k_mfma_f32_lat<32>, g, dim3(512), 0, E->stream, a, kchunk);
+          else hipLaunchKernelGGL(k_mfma_f32_lat<64>, g, dim3(512), 0, E->stream, a, kchunk);
           break;
         }
         if (const int S = E->d_slab ? splitk_splits(st, R, E->n_cu, P.dtype, E->sw) : 0) {
@@ -449,8 +418,8 @@ static int exec_launch_steps(Exec* E) {
           sk.tiles_n = (int32_t)((st.N + 63) / 64);
           sk.tiles_per_replica = (int32_t)(st.Bt * sk.tiles_m * sk.tiles_n);
           used_tile(64, 64);
-          launch_sk(st.modeA, st.modeB, dim3((unsigned)((int64_t)sk.tiles_per_replica * sk.S * R)), strm, a, sk);
-          launch_splitk_reduce<float>(E, strm, E->step_partials[s], R, a, sk);
+          launch_sk(st.modeA, st.modeB, dim3((unsigned)((int64_t)sk.tiles_per_replica * sk.S * R)), E->stream, a, sk);
+          launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
           break;
         }
         a.tiles_n = (int32_t)((st.N + st.tileN - 1) / st.tileN);
@@ -461,7 +430,7 @@ static int exec_launch_steps(Exec* E) {
             E->dbg_tiles = (size_t)total;
           }
           a.dbg = E->d_dbg;
-          HIPCHECK(hipMemsetAsync(E->d_dbg, 0, E->dbg_tiles * 64, strm));
+          HIPCHECK(hipMemsetAsync(E->d_dbg, 0, E->dbg_tiles * 64, E->stream));
         }
         // large-tile LDS-DMA variant (kernels_mfma_g.h) where the step's shape allows it.
         // CTN_MFMA_G (read when the executor is created): 0 = never, 1 = 256x128 tiles when the launch
@@ -492,7 +461,7 @@ static int exec_launch_steps(Exec* E) {
             a.tiles_n = (int32_t)(st.N / 256);
             a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
             hipLaunchKernelGGL((k_mfma_f32_g<8, 2, true>), dim3((unsigned)((int64_t)a.blocks_per_replica * R)), dim3(512), 0,
-                               strm, a);
+                               E->stream, a);
             break;
           }
           {
@@ -503,8 +472,8 @@ static int exec_launch_steps(Exec* E) {
             const bool use_asm = st.K % GK == 0 && !no_asm;
 #define CTN_G_LAUNCH(AA, BB)                                                                             \
             do {                                                                                         \
-              if (use_asm) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, AA, BB>), gg, dim3(256), 0, strm, a); \
-              else hipLaunchKernelGGL((k_mfma_f32_g<4, 2, false, AA, BB>), gg, dim3(256), 0, strm, a);        \
+              if (use_asm) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, AA, BB>), gg, dim3(256), 0, E->stream, a); \
+              else hipLaunchKernelGGL((k_mfma_f32_g<4, 2, false, AA, BB>), gg, dim3(256), 0, E->stream, a);        \
             } while (0)
             if (st.modeA == 2 && st.modeB == 1) CTN_G_LAUNCH(2, 1);
             else if (st.modeA == 1 && st.modeB == 2) CTN_G_LAUNCH(1, 2);
@@ -523,11 +492,11 @@ static int exec_launch_steps(Exec* E) {
           collapse_blocks = (int)(st.Bt * a.tiles_m * a.tiles_n);
           a.blocks_per_replica = collapse_blocks;
           a.partC_stride = collapse_blocks;
-          launch_mfma(st.modeA, st.modeB, row_tile, 64, dim3((unsigned)((int64_t)collapse_blocks * R)), strm, a, E->sw);
+          launch_mfma(st.modeA, st.modeB, row_tile, 64, dim3((unsigned)((int64_t)collapse_blocks * R)), E->stream, a, E->sw);
           break;
         }
         used_tile(row_tile, st.tileN);
-        launch_mfma(st.modeA, st.modeB, row_tile, st.tileN, dim3((unsigned)total), strm, a, E->sw);
+        launch_mfma(st.modeA, st.modeB, row_tile, st.tileN, dim3((unsigned)total), E->stream, a, E->sw);
         break;
       }
       case CTN_KERNEL_MFMA_F64: {
@@ -543,8 +512,8 @@ static int exec_launch_steps(Exec* E) {
           sk.tiles_n = (int32_t)((st.N + 63) / 64);
           sk.tiles_per_replica = (int32_t)(st.Bt * sk.tiles_m * sk.tiles_n);
           used_tile(64, 64);
-          launch_sk64(st.modeA, st.modeB, dim3((unsigned)((int64_t)sk.tiles_per_replica * sk.S * R)), strm, a, sk);
-          launch_splitk_reduce<double>(E, strm, E->step_partials[s], R, a, sk);
+          launch_sk64(st.modeA, st.modeB, dim3((unsigned)((int64_t)sk.tiles_per_replica * sk.S * R)), E->stream, a, sk);
+          launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
           break;
         }
         a.tiles_m = (int32_t)((st.M + kTile64M - 1) / kTile64M);
@@ -555,17 +524,17 @@ static int exec_launch_steps(Exec* E) {
             a.tiles_n = (int32_t)((st.N + DN - 1) / DN);
             a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
             const dim3 gg((unsigned)gtiles);
-            if (st.modeA == 2 && st.modeB == 2) hipLaunchKernelGGL((k_mfma_f64_g<2, 2>), gg, dim3(256), 0, strm, a);
-            else if (st.modeA == 2) hipLaunchKernelGGL((k_mfma_f64_g<2, 1>), gg, dim3(256), 0, strm, a);
-            else if (st.modeB == 2) hipLaunchKernelGGL((k_mfma_f64_g<1, 2>), gg, dim3(256), 0, strm, a);
-            else hipLaunchKernelGGL((k_mfma_f64_g<1, 1>), gg, dim3(256), 0, strm, a);
+            if (st.modeA == 2 && st.modeB == 2) hipLaunchKernelGGL((k_mfma_f64_g<2, 2>), gg, dim3(256), 0, E->stream, a);
+            else if (st.modeA == 2) hipLaunchKernelGGL((k_mfma_f64_g<2, 1>), gg, dim3(256), 0, E->stream, a);
+            else if (st.modeB == 2) hipLaunchKernelGGL((k_mfma_f64_g<1, 2>), gg, dim3(256), 0, E->stream, a);
+            else hipLaunchKernelGGL((k_mfma_f64_g<1, 1>), gg, dim3(256), 0, E->stream, a);
             break;
           }
         }
         used_tile(128, 64);
         a.tiles_n = (int32_t)((st.N + kTile64N - 1) / kTile64N);
         const dim3 g((unsigned)total), b(256);
-#define CTN_F64(AA, BB) hipLaunchKernelGGL((k_mfma_f64<AA, BB>), g, b, 0, strm, a)
+#define CTN_F64(AA, BB) hipLaunchKernelGGL((k_mfma_f64<AA, BB>), g, b, 0, E->stream, a)
         switch (st.modeA * 3 + st.modeB) {
           case 0: CTN_F64(0, 0); break; case 1: CTN_F64(0, 1); break; case 2: CTN_F64(0, 2); break;
           case 3: CTN_F64(1, 0); break; case 4: CTN_F64(1, 1); break; case 5: CTN_F64(1, 2); break;
@@ -583,16 +552,16 @@ static int exec_launch_steps(Exec* E) {
           sk.S = (int32_t)((st.K + sk.kchunk - 1) / sk.kchunk);
           const dim3 g((unsigned)((int64_t)st.blocks * sk.S), R);
           if (P.dtype == CTN_F32) {
-            hipLaunchKernelGGL(k_dot_split<float>, g, dim3(256), 0, strm, a, (float*)sk.slab, sk.numelC, sk.S, sk.kchunk);
-            launch_splitk_reduce<float>(E, strm, E->step_partials[s], R, a, sk);
+            hipLaunchKernelGGL(k_dot_split<float>, g, dim3(256), 0, E->stream, a, (float*)sk.slab, sk.numelC, sk.S, sk.kchunk);
+            launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
           } else {
-            hipLaunchKernelGGL(k_dot_split<double>, g, dim3(256), 0, strm, a, (double*)sk.slab, sk.numelC, sk.S, sk.kchunk);
-            launch_splitk_reduce<double>(E, strm, E->step_partials[s], R, a, sk);
+            hipLaunchKernelGGL(k_dot_split<double>, g, dim3(256), 0, E->stream, a, (double*)sk.slab, sk.numelC, sk.S, sk.kchunk);
+            launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
           }
           break;
         }
-        if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_dot<float>, dim3(st.blocks, R), dim3(256), 0, strm, a);
-        else hipLaunchKernelGGL(k_dot<double>, dim3(st.blocks, R), dim3(256), 0, strm, a);
+        if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_dot<float>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
+        else hipLaunchKernelGGL(k_dot<double>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
         break;
       case CTN_KERNEL_ROWDOT: {
         const int ks = E->d_slab ? rowdot_splits(st, R, E->n_cu) : 0;
@@ -605,20 +574,20 @@ static int exec_launch_steps(Exec* E) {
           a.ks_slab = sk.slab; a.ks_numelC = sk.numelC; a.ks_S = sk.S; a.ks_chunk = sk.kchunk;
         }
         const dim3 g(st.blocks, R, ks ? sk.S : 1);
-        if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_rowdot<float>, g, dim3(256), 0, strm, a);
-        else hipLaunchKernelGGL(k_rowdot<double>, g, dim3(256), 0, strm, a);
+        if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_rowdot<float>, g, dim3(256), 0, E->stream, a);
+        else hipLaunchKernelGGL(k_rowdot<double>, g, dim3(256), 0, E->stream, a);
         if (ks) {
           a.partC = part_dst; a.partC_stride = part_stride; reduced = true;
-          if (P.dtype == CTN_F32) launch_splitk_reduce<float>(E, strm, E->step_partials[s], R, a, sk);
-          else launch_splitk_reduce<double>(E, strm, E->step_partials[s], R, a, sk);
+          if (P.dtype == CTN_F32) launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
+          else launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
         }
         break;
       }
       default: {
         if (st.kvec) {   // short unit-stride K of the left operand: one output per thread, 16-byte loads along k
           a.dNv = make_fastdiv(st.Nv);
-          if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_stream_kvec<float>, dim3(st.blocks, R), dim3(256), 0, strm, a);
-          else hipLaunchKernelGGL(k_stream_kvec<double>, dim3(st.blocks, R), dim3(256), 0, strm, a);
+          if (P.dtype == CTN_F32) hipLaunchKernelGGL(k_stream_kvec<float>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
+          else hipLaunchKernelGGL(k_stream_kvec<double>, dim3(st.blocks, R), dim3(256), 0, E->stream, a);
           break;
         }
         // vector stores need a 16-byte aligned destination: the caller's final buffer may not be
@@ -639,7 +608,7 @@ static int exec_launch_steps(Exec* E) {
           a.ks_slab = sk.slab; a.ks_numelC = sk.numelC; a.ks_S = sk.S; a.ks_chunk = sk.kchunk;
         }
         const dim3 g(st.blocks, R, ks ? sk.S : 1), b(256);
-#define CTN_STREAM(TT, VV, UU) hipLaunchKernelGGL((k_stream<TT, VV, UU>), g, b, 0, strm, a)
+#define CTN_STREAM(TT, VV, UU) hipLaunchKernelGGL((k_stream<TT, VV, UU>), g, b, 0, E->stream, a)
         if (P.dtype == CTN_F32) {
           if (vw == 4) { if (u == 4) CTN_STREAM(float, 4, 4); else CTN_STREAM(float, 4, 1); }
           else { if (u == 4) CTN_STREAM(float, 1, 4); else CTN_STREAM(float, 1, 1); }
@@ -650,31 +619,27 @@ static int exec_launch_steps(Exec* E) {
 #undef CTN_STREAM
         if (ks) {
           a.partC = part_dst; a.partC_stride = part_stride; reduced = true;
-          if (P.dtype == CTN_F32) launch_splitk_reduce<float>(E, strm, E->step_partials[s], R, a, sk);
-          else launch_splitk_reduce<double>(E, strm, E->step_partials[s], R, a, sk);
+          if (P.dtype == CTN_F32) launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
+          else launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
         }
         break;
       }
     }
     if (st.collapse && !reduced)
-      hipLaunchKernelGGL(k_collapse, dim3(R), dim3(256), 0, strm, (const double*)E->d_scratch, collapse_blocks, part_dst);
+      hipLaunchKernelGGL(k_collapse, dim3(R), dim3(256), 0, E->stream, (const double*)E->d_scratch, collapse_blocks, part_dst);
     if (E->eager_rescale && P.stabilize && s + 1 < P.n_steps) {   // the final tensor is normalised by k_finalize
       const int64_t numel = P.tensors[st.out].numel;
       const int V = P.dtype == CTN_F64 ? 2 : 4;
       const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / V + 255) / 256, 2048)), R);
       if (P.dtype == CTN_F32)
-        hipLaunchKernelGGL(k_renorm<float>, g, dim3(256), 0, strm, (void* const*)E->d_ptrs, E->n_tensors, st.out, numel,
+        hipLaunchKernelGGL(k_renorm<float>, g, dim3(256), 0, E->stream, (void* const*)E->d_ptrs, E->n_tensors, st.out, numel,
                            (const double*)part_dst, E->step_partials[s], part_stride, P.min_norm);
       else
-        hipLaunchKernelGGL(k_renorm<double>, g, dim3(256), 0, strm, (void* const*)E->d_ptrs, E->n_tensors, st.out, numel,
+        hipLaunchKernelGGL(k_renorm<double>, g, dim3(256), 0, E->stream, (void* const*)E->d_ptrs, E->n_tensors, st.out, numel,
                            (const double*)part_dst, E->step_partials[s], part_stride, P.min_norm);
     }
-    if (timed) HIPCHECK(hipEventRecord(E->events[ev0 + 1], strm));
-    if (lanes && E->needs_event[s]) HIPCHECK(hipEventRecord(E->ev_done[s], strm));
+    if (timed) HIPCHECK(hipEventRecord(E->events[ev0 + 1], E->stream));
   }
-  if (lanes)   // join: the finishing passes on the main stream wait for the tail of every side lane
-    for (size_t ln = 1; ln < E->lane_tail.size(); ++ln)
-      if (E->lane_joined[ln] && E->lane_tail[ln] >= 0) HIPCHECK(hipStreamWaitEvent(E->stream, E->ev_done[E->lane_tail[ln]], 0));
   FinalArgs f;
   f.ptrs = E->d_ptrs;
   f.partials = E->d_partials;
@@ -731,13 +696,7 @@ static int exec_launch_all(Exec* E) {
       E->use_graph = 0;
       return exec_launch_steps(E);
     }
-    E->capturing_lanes = !E->side.empty();
-    if (E->capturing_lanes) {
-      std::fill(E->lane_joined.begin(), E->lane_joined.end(), 0);
-      if (hipEventRecord(E->ev_fork, E->stream) != hipSuccess) { (void)hipGetLastError(); E->capturing_lanes = false; }
-    }
     const int rc = exec_launch_steps(E);
-    E->capturing_lanes = false;
     const hipError_t ec = hipStreamEndCapture(E->stream, &g);
     if (rc != CTN_OK || ec != hipSuccess || !g ||
         hipGraphInstantiate(&E->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
@@ -959,66 +918,6 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     HIPCHECK_X(hipMemcpy(E.d_stepOff, E.step_off.data(), P.n_steps * 8, hipMemcpyHostToDevice));
     HIPCHECK_X(hipMemcpy(E.d_stepSlots, slots.data(), P.n_steps * 4, hipMemcpyHostToDevice));
   }
-  // ---- DAG lanes for the captured graph (CTN_LANES side streams; see exec_launch_steps) ---------------------
-  // A step continues the lane of an operand's producer when that producer is still the lane's tail (no event
-  // needed), else - a step on inputs only, or one whose producers' lanes have moved on - it opens the least
-  // recently used side lane.  Steps that use the executor-wide scratch (collapse partials, split-K slabs) stay on
-  // the main stream, which orders them among themselves.
-  if (E.sw.lanes > 0 && E.use_graph && !P.chain && P.n_steps >= 8) {
-    const int NL = E.sw.lanes + 1;
-    E.lane.assign(P.n_steps, 0);
-    E.deps.assign(P.n_steps, {});
-    E.needs_event.assign(P.n_steps, 0);
-    E.lane_tail.assign(NL, -1);
-    E.lane_joined.assign(NL, 0);
-    std::vector<int> last_use(NL, -1);
-    auto uses_scratch = [&](const Step& st) {
-      if (st.collapse) return true;
-      if (lat_form(st, replicas, E.n_cu, P.dtype, E.sw)) return false;
-      return splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
-             rowdot_splits(st, replicas, E.n_cu);
-    };
-    int side_lanes_used = 0;
-    for (int s = 0; s < P.n_steps; ++s) {
-      const Step& st = P.steps[s];
-      for (int id : {st.lhs, st.rhs})
-        if (id >= P.n_inputs) E.deps[s].push_back(P.tensors[id].producer);
-      for (int d : st.mem_deps)
-        if (std::find(E.deps[s].begin(), E.deps[s].end(), d) == E.deps[s].end()) E.deps[s].push_back(d);
-      int ln = -1;
-      if (uses_scratch(st)) ln = 0;
-      if (ln < 0)
-        for (int id : {st.lhs, st.rhs})
-          if (id >= P.n_inputs) {
-            const int p = P.tensors[id].producer;
-            if (E.lane_tail[E.lane[p]] == p && (ln < 0 || P.steps[p].flops > P.steps[E.lane_tail[ln]].flops)) ln = E.lane[p];
-          }
-      if (ln < 0) {   // open the least recently used lane (lane 0 competes too: a sequential chain stays on it)
-        ln = 0;
-        for (int l = 1; l < NL; ++l)
-          if (last_use[l] < last_use[ln]) ln = l;
-      }
-      E.lane[s] = ln;
-      E.lane_tail[ln] = s;
-      last_use[ln] = s;
-      if (ln > 0) side_lanes_used = std::max(side_lanes_used, ln);
-    }
-    for (int s = 0; s < P.n_steps; ++s)
-      for (int d : E.deps[s])
-        if (E.lane[d] != E.lane[s]) E.needs_event[d] = 1;
-    for (int l = 1; l < NL; ++l)
-      if (E.lane_tail[l] >= 0) E.needs_event[E.lane_tail[l]] = 1;
-    if (side_lanes_used > 0) {
-      E.side.assign(side_lanes_used, nullptr);
-      for (auto& st_ : E.side) HIPCHECK_X(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
-      E.ev_done.assign(P.n_steps, nullptr);
-      for (int s = 0; s < P.n_steps; ++s)
-        if (E.needs_event[s]) HIPCHECK_X(hipEventCreateWithFlags(&E.ev_done[s], hipEventDisableTiming));
-      HIPCHECK_X(hipEventCreateWithFlags(&E.ev_fork, hipEventDisableTiming));
-    } else {
-      E.lane.clear();   // a pure chain: nothing to overlap
-    }
-  }
   HIPCHECK_X(hipMalloc((void**)&E.d_log, (size_t)replicas * 8));
   HIPCHECK_X(hipMalloc((void**)&E.d_resc, (size_t)replicas * P.n_steps * 8));
   HIPCHECK_X(hipMalloc((void**)&E.d_logs, (size_t)replicas * P.n_steps * 8));
@@ -1166,8 +1065,6 @@ int ctn_exec_set_rescale_mode(ctn_exec* exec, int mode) {
 }
 
 int ctn_exec_eager_reruns(const ctn_exec* exec) { return exec ? exec->e.eager_reruns : CTN_INVALID_ARG; }
-
-int ctn_exec_lanes(const ctn_exec* exec) { return exec ? 1 + (int)exec->e.side.size() : CTN_INVALID_ARG; }
 
 int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space, void* const* outs,
                  int outs_space, double* log_scale, double* step_rescales) {

@@ -69,26 +69,8 @@ struct Arena {
     top += bytes;
     return off;
   }
-  // who made a region reusable: (offset, size, step that consumed the tensor which lived there).  A later tensor
-  // placed over such a region must not be written before that step has finished reading - in plan order that is
-  // automatic, but an executor that runs independent steps concurrently needs the edge (Step::mem_deps).
-  struct Freed { int64_t off, size; int step; };
-  std::vector<Freed> history;
-  void overlapping(int64_t off, int64_t bytes, std::vector<int>& steps) {
+  void release(int64_t off, int64_t bytes) {
     bytes = round_up(std::max<int64_t>(bytes, 1), kAlign);
-    for (size_t i = 0; i < history.size();) {
-      const Freed& f = history[i];
-      if (f.off < off + bytes && off < f.off + f.size) {
-        if (std::find(steps.begin(), steps.end(), f.step) == steps.end()) steps.push_back(f.step);
-        // the new tenant's own consumer will be recorded when IT is released: this entry is spent if fully covered
-        if (f.off >= off && f.off + f.size <= off + bytes) { history.erase(history.begin() + i); continue; }
-      }
-      ++i;
-    }
-  }
-  void release(int64_t off, int64_t bytes, int step = -1) {
-    bytes = round_up(std::max<int64_t>(bytes, 1), kAlign);
-    if (step >= 0) history.push_back({off, bytes, step});
     free_list.push_back({off, bytes});
     std::sort(free_list.begin(), free_list.end(),
               [](const Block& a, const Block& b) { return a.off < b.off; });
@@ -457,12 +439,9 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     build_table(gk, 1, padK, tb);  st.t.okB = append(P.tables, tb);
 
     // -- workspace: allocate the output, then release the consumed intermediates
-    if (!last) {
-      out.ws_offset = arena.alloc(out.numel * es);
-      arena.overlapping(out.ws_offset, out.numel * es, st.mem_deps);
-    }
+    if (!last) out.ws_offset = arena.alloc(out.numel * es);
     for (int id : {lhs, rhs}) {
-      if (id >= d.n_inputs) arena.release(P.tensors[id].ws_offset, P.tensors[id].numel * es, s);
+      if (id >= d.n_inputs) arena.release(P.tensors[id].ws_offset, P.tensors[id].numel * es);
     }
     P.tensors.push_back(std::move(out));
     P.steps.push_back(std::move(st));

@@ -66,8 +66,6 @@ struct Step {
   int partials = 1;    // partial abs-sums per replica after the optional collapse pass
   bool collapse = false;
   double flops = 0;
-  std::vector<int> mem_deps;  // steps that read the workspace region this step's output re-uses: they must have finished
-                              // before this step writes (only matters to an executor that overlaps independent steps)
   TableRefs t;
 };
 

@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "ctn_plan_workspace_bytes", "ctn_plan_step_info",
     "ctn_exec_create", "ctn_exec_destroy", "ctn_exec_run", "ctn_exec_enqueue",
     "ctn_exec_fetch", "ctn_exec_synchronize", "ctn_exec_set_timing", "ctn_exec_step_ms",
-    "ctn_exec_step_tile", "ctn_exec_set_rescale_mode", "ctn_exec_eager_reruns", "ctn_exec_lanes",
+    "ctn_exec_step_tile", "ctn_exec_set_rescale_mode", "ctn_exec_eager_reruns",
 )
 
 
@@ -151,7 +151,6 @@ def load_library():
         "ctn_exec_step_tile": (i32, [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "ctn_exec_set_rescale_mode": (i32, [vp, i32]),
         "ctn_exec_eager_reruns": (i32, [vp]),
-        "ctn_exec_lanes": (i32, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -350,10 +349,6 @@ class Executor:
     def eager_reruns(self):
         """How often a fetch found a lazily rescaled product out of range and repeated the contraction eagerly."""
         return _check(self._lib.ctn_exec_eager_reruns(self._h))
-
-    def lanes(self):
-        """Streams the captured launch graph spreads over (1 = strictly sequential)."""
-        return _check(self._lib.ctn_exec_lanes(self._h))
 
     def set_timing(self, slots):
         """Bracket every step of the next ``slots`` enqueues with HIP events (0 = off)."""

@@ -171,14 +171,6 @@ int ctn_exec_set_rescale_mode(ctn_exec* exec, int mode);
 int ctn_exec_eager_reruns(const ctn_exec* exec);
 
 /*
- * Streams the executor's captured launch graph spreads over: 1 = every step after the other (a chain, or
- * CTN_LANES=0), more = independent branches of the contraction tree run as parallel branches of the hipGraph
- * (a step waits for exactly its operands' producers and for the last readers of the workspace it re-uses).
- * Results do not depend on it: no kernel uses atomics, every reduction has a fixed order.
- */
-int ctn_exec_lanes(const ctn_exec* exec);
-
-/*
  * Workgroup tile (rows, columns) of the MFMA kernel that the LAST enqueue launched for `step`
  * (0, 0 for non-MFMA steps or before the first enqueue).  The planner's choice (ctn_step_info.tile_m/n)
  * can be overridden at launch time by the number of replicas: few tiles -> 64 x 64 split-K or 128 x 64,

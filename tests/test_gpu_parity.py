@@ -401,7 +401,7 @@ def test_latency_mode_split_k(dtype, tol, einstr, shapes, monkeypatch):
     ("kam,kbn->ambn", [(136, 4, 24), (136, 2, 40)], 1, (16, 16)),  # composite free indices, strided C
     ("km,kn->mn", [(4096, 64), (4096, 64)], 1, (16, 16)),      # K = 4096: both tables fill their LDS arrays
     ("km,kn->mn", [(130, 512), (130, 400)], 3, (32, 32)),      # 3 x 208 tiles of 32: odd k chunk (17 -> 18)
-    ("km,kn->mn", [(130, 512), (130, 512)], 5, (64, 64)),      # 5 x 64 tiles of 64: k chunk 65 -> 66
+    ("km,kn->mn", [(130, 512), (130, 448)], 5, (64, 64)),      # 5 x 56 tiles of 64: k chunk 65 -> 66
 ])
 def test_latency_mode_one_launch(einstr, shapes, replicas, tile):
     """A few networks in flight, fp32: the step runs as ONE launch of k_mfma_f32_lat - K split over the eight waves
@@ -500,40 +500,6 @@ def test_graph_replay_matches_eager_and_follows_new_operands(monkeypatch):
     t0, c0 = bc0.run_host(sets)
     assert np.array_equal(t0, runs[0][0]) and np.array_equal(c0, runs[0][1])
     bc0.executor.close()
-
-
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_independent_branches_run_as_parallel_graph_branches(dtype, monkeypatch):
-    """A PEPS tree has independent branches (site x vector absorptions, row blocks): in the captured graph they sit
-    on side streams and wait only for what they depend on - operand producers and the last readers of re-used
-    workspace.  The results must be the SAME BITS as the strictly sequential launch order, every time."""
-    from tests import networks as nets
-    from contractn_amd import TN
-
-    tn = nets.peps_closed(TN, 5, 5, 5, dtype=dtype, seed=8)
-    ops = [np.asarray(p, dtype=dtype) for p in tn.params]
-    shapes = [o.shape for o in ops]
-    rng = np.random.default_rng(3)
-    sets = [[(o * rng.uniform(0.5, 2.0)).astype(dtype) for o in ops] for _ in range(3)]
-    bc = E.BatchedContraction(tn.einsum_str, shapes, dtype, optimize="auto", replicas=3)
-    assert bc.executor.lanes() > 1
-    runs = [bc.run_host(sets) for _ in range(12)]          # 2 eager enqueues, then 10 replays of the branched graph
-    for t, c in runs[1:]:
-        assert np.array_equal(t, runs[0][0]) and np.array_equal(c, runs[0][1])
-    bc.executor.close()
-    monkeypatch.setenv("CTN_LANES", "0")
-    seq = E.BatchedContraction(tn.einsum_str, shapes, dtype, optimize="auto", replicas=3)
-    assert seq.executor.lanes() == 1
-    for _ in range(4):
-        t, c = seq.run_host(sets)
-        assert np.array_equal(t, runs[0][0]) and np.array_equal(c, runs[0][1])
-    seq.executor.close()
-    # and the value is right
-    from oracle import cpu_ref
-    from contractn_amd.paths import ssa_to_linear
-    rt, rc = cpu_ref.contract(tn.einsum_str, *sets[1], path=ssa_to_linear(nets.peps_row_path(5, 5), 50), split_format=True)
-    assert float(runs[0][0][1]) == float(rt)
-    assert abs(float(runs[0][1][1]) - float(rc)) <= (1e-4 if dtype == np.float32 else 1e-10) * max(1.0, abs(float(rc)))
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-12)])
