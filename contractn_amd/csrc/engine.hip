@@ -177,6 +177,7 @@ static void launch_mfma_a(int ma, int mb, dim3 grid, hipStream_t st, const StepA
   switch (ma) {
     case 1: launch_mfma_b<1, BK, TN, TM>(mb, grid, st, a); break;
     case 2: launch_mfma_b<2, BK, TN, TM>(mb, grid, st, a); break;
+    case 3: launch_mfma_b<3, BK, TN, TM>(mb, grid, st, a); break;   // A = X (.) Y formed while staging (fused step)
     default: launch_mfma_b<0, BK, TN, TM>(mb, grid, st, a); break;
   }
 }
@@ -211,7 +212,7 @@ static void launch_mfma(int ma, int mb, int tile_m, int tile_n, dim3 grid, hipSt
 static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
   const int mode = sw.splitk;
   const bool mfma = (dtype == CTN_F32 && st.kernel == CTN_KERNEL_MFMA_F32) || (dtype == CTN_F64 && st.kernel == CTN_KERNEL_MFMA_F64);
-  if (mode == 0 || !mfma || st.collapse || st.K < 128) return 0;
+  if (mode == 0 || !mfma || st.collapse || st.K < 128 || st.modeA == 3) return 0;
   const int max_tiles = sw.splitk_max;
   const int64_t limit = max_tiles > 0 ? max_tiles : n_cu / 2;
   if (mode != 1 && (int64_t)st.blocks * R > limit) return 0;
@@ -228,7 +229,7 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSw
 // 16 x 16: on 64 tiles of 32 x 32 three quarters of the matrix pipes idle and the step takes 14 us instead of ~6);
 // at most kMaxPartials tiles per replica (one abs-sum partial each), both k-offset tables in LDS.
 static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
-  if (sw.lat == 0 || dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.rhs < 0) return 0;
+  if (sw.lat == 0 || dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.rhs < 0 || st.modeA == 3) return 0;
   if (st.K > kLatMaxK || st.K < 32) return 0;
   if (sw.lat != 1 && ((int64_t)st.blocks * R > n_cu / 2 || st.K < 128)) return 0;
   auto tiles = [&](int T) { return st.Bt * ((st.M + T - 1) / T) * ((st.N + T - 1) / T); };
@@ -239,6 +240,27 @@ static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitche
   if (t32 <= kMaxPartials) return 32;
   if (t64 <= kMaxPartials && st.K <= 2 * 512) return 64;
   return 0;
+}
+
+// Tile of the register-staged fp32 kernel for this step and replica count: the planner's 128 / 64 choice, halved
+// (rows or columns, the larger extent first) while the launch has fewer than two workgroups per CU - one network with
+// a batch leg, or a fused step whose output is a quarter of the GEMM it replaced - as long as the tile count still
+// fits the step's partial-sum region.  Steps the planner made eligible for the large-tile kernel keep 128-unit
+// counting (their fallback must agree with it), and so do steps that already go through the collapse pass.
+static void plain_tiles(const Step& st, int R, int n_cu, int* tm, int* tn) {
+  *tm = st.tileM == 64 ? 64 : kTileM;
+  *tn = st.tileN;
+  if (st.kernel != CTN_KERNEL_MFMA_F32 || st.tileM == 256 || st.collapse) return;
+  auto tiles = [&](int a, int b) { return st.Bt * ((st.M + a - 1) / a) * ((st.N + b - 1) / b); };
+  while (tiles(*tm, *tn) * R < 2LL * n_cu) {
+    int a = *tm, b = *tn;
+    if (a == 128 && (b == 64 || st.M >= st.N) && st.M > 64) a = 64;
+    else if (b == 128 && st.N > 64) b = 64;
+    else if (a == 128 && st.M > 64) a = 64;
+    else break;
+    if (tiles(a, b) > kMaxPartials) break;
+    *tm = a; *tn = b;
+  }
 }
 
 // the reduce pass of a split-K step: fold 16 to 1 while more than 16 slabs are left (ping-pong between the two
@@ -340,6 +362,14 @@ static int exec_launch_steps(Exec* E) {
   }
   for (int s = 0; s < P.n_steps && !chain; ++s) {
     const Step& st = P.steps[s];
+    if (st.kernel == CTN_KERNEL_FUSED) {   // formed on the fly inside its consumer: nothing to launch
+      if (E->timing_runs < E->timing_slots) {
+        const size_t e0 = ((size_t)E->timing_runs * P.n_steps + s) * 2;
+        HIPCHECK(hipEventRecord(E->events[e0], E->stream));
+        HIPCHECK(hipEventRecord(E->events[e0 + 1], E->stream));
+      }
+      continue;
+    }
     StepArgs a;
     const int32_t* T = E->d_tables;
     a.obA = T + st.t.obA; a.obB = T + st.t.obB; a.obC = T + st.t.obC;
@@ -349,7 +379,7 @@ static int exec_launch_steps(Exec* E) {
     a.ptrs = E->d_ptrs;
     auto part_of = [&](int id, const double** p, int32_t* cnt, int32_t* stride, double* numel) {
       *p = nullptr; *cnt = 0; *stride = 0; *numel = 1;
-      if (id >= P.n_inputs && P.stabilize && !E->eager_rescale) {
+      if (id >= P.n_inputs && P.stabilize && !E->eager_rescale && P.steps[P.tensors[id].producer].kernel != CTN_KERNEL_FUSED) {
         const int ps = P.tensors[id].producer;
         *p = E->d_partials + (size_t)E->step_off[ps] * R;
         *cnt = *stride = E->step_partials[ps];
@@ -358,6 +388,9 @@ static int exec_launch_steps(Exec* E) {
     };
     part_of(st.lhs, &a.partA, &a.PA, &a.strideA, &a.numelA);
     part_of(st.rhs, &a.partB, &a.PB, &a.strideB, &a.numelB);
+    part_of(st.lhs2, &a.partA2, &a.PA2, &a.strideA2, &a.numelA2);
+    a.obA2 = T + st.t.obA2; a.omA2 = T + st.t.omA2; a.okA2 = T + st.t.okA2;
+    a.idA2 = st.lhs2 >= 0 ? st.lhs2 : E->n_tensors - 1;
     double* part_dst = E->d_partials + (size_t)E->step_off[s] * R;
     const int part_stride = E->step_partials[s];    // slots per replica of this step's region
     a.partC = st.collapse ? E->d_scratch : part_dst;
@@ -483,20 +516,15 @@ static int exec_launch_steps(Exec* E) {
           }
           break;
         }
-        // under-filled launch (fewer than two 128 x 128 tiles per CU, e.g. one network with a batch
-        // leg): 128 x 64 tiles double the workgroups.  Only for steps whose partials go through the
-        // collapse pass anyway (> 64 tiles per replica), where the tile count is not baked into the plan.
-        if (st.collapse && st.tileN == kTileN && total < 2LL * E->n_cu && st.N > 64) {
-          used_tile(row_tile, 64);
-          a.tiles_n = (int32_t)((st.N + 63) / 64);
-          collapse_blocks = (int)(st.Bt * a.tiles_m * a.tiles_n);
-          a.blocks_per_replica = collapse_blocks;
-          a.partC_stride = collapse_blocks;
-          launch_mfma(st.modeA, st.modeB, row_tile, 64, dim3((unsigned)((int64_t)collapse_blocks * R)), E->stream, a, E->sw);
-          break;
-        }
-        used_tile(row_tile, st.tileN);
-        launch_mfma(st.modeA, st.modeB, row_tile, st.tileN, dim3((unsigned)total), E->stream, a, E->sw);
+        // register-staged tiles; halved (128 -> 64 rows / columns) while the launch is under-filled - see plain_tiles
+        int tm = row_tile, tn = st.tileN;
+        plain_tiles(st, R, E->n_cu, &tm, &tn);
+        a.tiles_m = (int32_t)((st.M + tm - 1) / tm);
+        a.tiles_n = (int32_t)((st.N + tn - 1) / tn);
+        a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
+        if (!st.collapse) a.partC_stride = part_stride;       // == blocks_per_replica (ctn_exec_create used the same rule)
+        used_tile(tm, tn);
+        launch_mfma(st.modeA, st.modeB, tm, tn, dim3((unsigned)((int64_t)a.blocks_per_replica * R)), E->stream, a, E->sw);
         break;
       }
       case CTN_KERNEL_MFMA_F64: {
@@ -906,6 +934,11 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     else if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
                           rowdot_splits(st, replicas, E.n_cu)))
       E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kWaveOutputs, P.tensors[st.out].numel / 1024));
+    else if (st.kernel == CTN_KERNEL_MFMA_F32 && !st.collapse && st.tileM != 256) {
+      int tm, tn;
+      plain_tiles(st, replicas, E.n_cu, &tm, &tn);
+      E.step_partials[s] = (int)(st.Bt * ((st.M + tm - 1) / tm) * ((st.N + tn - 1) / tn));
+    }
     E.step_off[s] = E.part_slots;
     E.part_slots += E.step_partials[s];
   }
@@ -929,7 +962,10 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   }
   std::vector<int32_t> sp(P.n_steps);
   std::vector<double> sn(P.n_steps);
-  for (int s = 0; s < P.n_steps; ++s) { sp[s] = E.step_partials[s]; sn[s] = (double)P.tensors[P.steps[s].out].numel; }
+  for (int s = 0; s < P.n_steps; ++s) {
+    sp[s] = P.steps[s].kernel == CTN_KERNEL_FUSED ? 0 : E.step_partials[s];   // no partials: rescale reported as 0.0
+    sn[s] = (double)P.tensors[P.steps[s].out].numel;
+  }
   HIPCHECK_X(hipMalloc((void**)&E.d_stepP, P.n_steps * 4));
   HIPCHECK_X(hipMalloc((void**)&E.d_stepNumel, P.n_steps * 8));
   HIPCHECK_X(hipMemcpy(E.d_stepP, sp.data(), P.n_steps * 4, hipMemcpyHostToDevice));
@@ -1013,7 +1049,8 @@ static bool exec_scales_suspect(const Exec* E) {
         const double v = rs[P.tensors[id].producer];
         return v == 0.0 ? 1.0 : v;
       };
-      const double sab = scale_of(st.lhs) * (st.rhs >= 0 ? scale_of(st.rhs) : 1.0);
+      if (st.kernel == CTN_KERNEL_FUSED) continue;
+      const double sab = scale_of(st.lhs) * (st.rhs >= 0 ? scale_of(st.rhs) : 1.0) * (st.lhs2 >= 0 ? scale_of(st.lhs2) : 1.0);
       const double so = rs[s];
       if (!std::isfinite(so) || !std::isfinite(sab)) return true;
       if (so == 0.0) { if (sab > zhi || sab < zlo) return true; continue; }

@@ -60,6 +60,12 @@ struct StepArgs {
   void* ks_slab;
   int64_t ks_numelC;
   int32_t ks_S, ks_chunk;
+  // fused element-wise product as the A operand ("KR", mode_a = 3): A[m][k] = X[..] * Y[..]; X is described by the
+  // A fields above, Y by these
+  const int32_t *obA2, *omA2, *okA2;
+  const double* partA2;
+  double numelA2;
+  int32_t idA2, PA2, strideA2;
 };
 
 struct FinalArgs {

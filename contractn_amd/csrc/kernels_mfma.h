@@ -138,13 +138,73 @@ struct TileLoader {
   }
 };
 
+// MODE 3 ("KR"): the A operand is the element-wise product of TWO tensors, X (.) Y, formed while the tile is staged -
+// a Khatri-Rao / Hadamard / broadcast product (reference einsum.py:382-384: `ad,ac->acd`, `bl,bp->bpl`) that the
+// planner fused into the GEMM consuming it, so the product tensor never exists in memory (CP with r = n = 1024:
+// a 4 GiB intermediate; r = 4096: 2^32 elements, which no buffer of this engine could even hold).  Every A element
+// is X[omX[m] + okX[k]] * Y[omY[m] + okY[k]]: two scalar gathers from small, cache-resident tensors (a label that
+// an operand does not carry has stride 0 in its tables).  LDS image [k][rows], like mode 0.
+template <int BK, int ROWS>
+struct TileLoaderKR {
+  static constexpr int NV = ROWS * BK / 256;
+  static constexpr int KPP = 256 / ROWS;
+  static constexpr int kSize = BK * ROWS;
+  float v[NV], v2[NV];
+  int kofs[NV], kofs2[NV];
+  int offm, offm2;
+  bool okm;
+  const int32_t* __restrict__ ok2;
+  const float* __restrict__ base2;
+
+  __device__ __forceinline__ void init(const int32_t* __restrict__ om, int m0, int M, int tid) {
+    const int gm = m0 + (tid % ROWS);
+    offm = om[gm];
+    okm = gm < M;
+  }
+  __device__ __forceinline__ void init2(const int32_t* __restrict__ om2, const int32_t* __restrict__ ok2_,
+                                        const float* __restrict__ base2_, int m0, int tid) {
+    offm2 = om2[m0 + (tid % ROWS)];
+    ok2 = ok2_;
+    base2 = base2_;
+  }
+  __device__ __forceinline__ void tab(const int32_t* __restrict__ ok, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      kofs[i] = ok[k0 + tid / ROWS + KPP * i];
+      kofs2[i] = ok2[k0 + tid / ROWS + KPP * i];
+    }
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ base) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i] = base[offm + kofs[i]];
+      v2[i] = base2[offm2 + kofs2[i]];
+    }
+  }
+  template <bool FULL>
+  __device__ __forceinline__ void store(float* __restrict__ s, int k0, int K, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int kr = tid / ROWS + KPP * i;
+      const bool in = FULL || (okm && (k0 + kr) < K);
+      s[kr * ROWS + (tid % ROWS)] = in ? v[i] * v2[i] : 0.f;
+    }
+  }
+  static __device__ __forceinline__ int idx(int row, int k) { return k * ROWS + row; }
+};
+
+template <int MODE, int BK, int ROWS>
+struct LoaderOf { typedef TileLoader<MODE, BK, ROWS> type; };
+template <int BK, int ROWS>
+struct LoaderOf<3, BK, ROWS> { typedef TileLoaderKR<BK, ROWS> type; };
+
 template <int MA, int MB, int BK, int TN, bool FULL, int BM>
-__device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLoader<MB, BK, TN>& lb,
+__device__ __forceinline__ void mfma_mainloop(typename LoaderOf<MA, BK, BM>::type& la, TileLoader<MB, BK, TN>& lb,
                                               const float* __restrict__ A, const float* __restrict__ B,
                                               const int32_t* __restrict__ okA, const int32_t* __restrict__ okB,
                                               int K, float* sA, float* sB, f32x16 (&acc)[BM / 64][TN / 64], int tid,
                                               unsigned long long* dbg1) {
-  using LA = TileLoader<MA, BK, BM>;
+  using LA = typename LoaderOf<MA, BK, BM>::type;
   using LB = TileLoader<MB, BK, TN>;
   constexpr int SZA = LA::kSize, SZB = LB::kSize;
   constexpr int NJ = TN / 64;  // 32-wide column blocks per wave
@@ -174,7 +234,7 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLo
   int fbx[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) fbx[j] = LB::idx(wn + j * 32 + l31, h);
-  constexpr int stepA = MA == 2 ? 2 : 2 * BM;  // advance of the fragment index per k-step (k += 2)
+  constexpr int stepA = MA == 2 ? 2 : 2 * BM;  // advance of the fragment index per k-step (k += 2); KR: [k][rows] like mode 0
   constexpr int stepB = MB == 2 ? 2 : 2 * TN;
 
   for (int kt = 0; kt < nkt; ++kt) {
@@ -226,7 +286,7 @@ __device__ __forceinline__ void mfma_mainloop(TileLoader<MA, BK, BM>& la, TileLo
 template <int MA, int MB, int BK, int TN, int BM = kTileM>
 __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a) {
   static_assert((BM == 128 || BM == 64) && (TN == 128 || TN == 64), "tile shapes");
-  using LA = TileLoader<MA, BK, BM>;
+  using LA = typename LoaderOf<MA, BK, BM>::type;
   using LB = TileLoader<MB, BK, TN>;
   constexpr int SZA = LA::kSize, SZB = LB::kSize;
   constexpr int NJ = TN / 64;
@@ -258,8 +318,10 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 0] = __builtin_amdgcn_s_memtime();
 #endif
-  const float scA = producer_scale<float>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
+  float scA = producer_scale<float>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
   const float scB = producer_scale<float>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
+  float scA2 = 1.f;
+  if constexpr (MA == 3) scA2 = producer_scale<float>(a.partA2, a.PA2, a.strideA2, a.numelA2, a.min_norm, r);
 
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
@@ -272,6 +334,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   LA la;
   LB lb;
   la.init(a.omA, m0, a.M, tid);
+  if constexpr (MA == 3) la.init2(a.omA2, a.okA2, (const float*)tp[a.idA2] + a.obA2[b], m0, tid);
   lb.init(a.onB, n0, a.N, tid);
 
   const int lane = tid & 63, w = tid >> 6;
@@ -300,7 +363,8 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
 #endif
 
   // epilogue: lazy rescale, store through the C offset tables, abs-sum partial
-  const float iA = 1.0f / scA, iB = 1.0f / scB;
+  // (KR: both factors of the A operand carry a rescale; folded into one multiplier)
+  const float iA = MA == 3 ? (1.0f / scA) * (1.0f / scA2) : 1.0f / scA, iB = 1.0f / scB;
   float asum = 0.f;
   {
     // Each WAVE stages its own 64 x TN/2 accumulator block through its quarter of the (now idle)

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <numeric>
 
@@ -16,6 +17,8 @@ struct LabelInfo {
   int64_t ext = 0;
   int64_t sA = 0, sB = 0, sC = 0;
   bool inA = false, inB = false, inC = false;
+  int64_t sA2 = 0;      // fused steps: stride in the SECOND tensor of the A side (A = X (.) Y); sA is X's
+  bool inX = false, inA2 = false;  // fused steps: label carried by X / by Y (inA = either)
   int firstPos = 0;  // for stable ordering
   int cls = kK;
 };
@@ -38,7 +41,7 @@ void build_table(const std::vector<const LabelInfo*>& group, int which /*0 A,1 B
   for (int64_t i = 0; i < n; ++i) {
     int64_t off = 0;
     for (size_t j = 0; j < group.size(); ++j) {
-      int64_t s = which == 0 ? group[j]->sA : which == 1 ? group[j]->sB : group[j]->sC;
+      int64_t s = which == 0 ? group[j]->sA : which == 1 ? group[j]->sB : which == 2 ? group[j]->sC : group[j]->sA2;
       off += idx[j] * s;
     }
     out[i] = (int32_t)off;
@@ -148,6 +151,98 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
   }
   P.input_bytes_per_replica = in_bytes;
 
+  // ---- fusion pre-pass -----------------------------------------------------------
+  // An element-wise product (Khatri-Rao / Hadamard / broadcast: no label summed) whose result only feeds a GEMM
+  // is formed on the fly as that GEMM's A operand (pattern A: CP decomposition, `ad,ac->acd` then `acd,ae->cde`);
+  // a GEMM whose result is only re-weighted and summed by a small tensor (`bl,plr->bpr` then `bpr,bp->br`: an MPS
+  // site applied to a batch of inputs, reference paper Fig. 1d) is the same triple product regrouped (pattern B:
+  // (v (.) x) . A).  Either way the intermediate - 4 GiB for CP with r = n = 1024 - never exists.  fp32 only (the
+  // KR loader lives in k_mfma_f32); CTN_FUSE=0 disables, 1 fuses whenever the pattern matches (tests).
+  struct Fuse { int x = -1, y = -1, w = -1; };
+  std::vector<Fuse> fuse(d.n_steps);
+  std::vector<char> absorbed(d.n_steps, 0);
+  {
+    const char* fe = getenv("CTN_FUSE");
+    const int fmode = fe ? atoi(fe) : -1;
+    if (P.dtype == CTN_F32 && fmode != 0) {
+      const int nt = d.n_inputs + d.n_steps;
+      std::vector<std::vector<int32_t>> labs(nt);
+      std::vector<double> numel(nt, 1.0);
+      {
+        int64_t c = 0;
+        for (int i = 0; i < d.n_inputs; ++i) {
+          for (int a = 0; a < d.in_ndim[i]; ++a) labs[i].push_back(d.in_labels[c + a]);
+          c += d.in_ndim[i];
+        }
+        c = 0;
+        for (int s = 0; s < d.n_steps; ++s) {
+          for (int a = 0; a < d.step_out_ndim[s]; ++a) labs[d.n_inputs + s].push_back(d.step_out_labels[c + a]);
+          c += d.step_out_ndim[s];
+        }
+        for (int i = 0; i < nt; ++i)
+          for (int32_t l : labs[i]) { auto it = label_ext.find(l); numel[i] *= it == label_ext.end() ? 1.0 : (double)it->second; }
+      }
+      auto has = [&](int id, int32_t l) { return std::find(labs[id].begin(), labs[id].end(), l) != labs[id].end(); };
+      auto distinct = [&](int id) {
+        for (size_t a = 0; a < labs[id].size(); ++a)
+          for (size_t b = a + 1; b < labs[id].size(); ++b) if (labs[id][a] == labs[id][b]) return false;
+        return true;
+      };
+      auto ext = [&](int32_t l) { auto it = label_ext.find(l); return it == label_ext.end() ? (int64_t)1 : it->second; };
+      std::vector<int> consumer(nt, -1);
+      for (int s = 0; s < d.n_steps; ++s) {
+        if (d.step_lhs[s] >= 0 && d.step_lhs[s] < nt) consumer[d.step_lhs[s]] = s;
+        if (d.step_rhs[s] >= 0 && d.step_rhs[s] < nt) consumer[d.step_rhs[s]] = s;
+      }
+      // is (x (.) y) . w -> out a GEMM the tile kernel takes?  M from x/y, N from w only, K summed
+      auto gemm_ok = [&](int x, int y, int w, int out) {
+        int64_t M = 1, N = 1, K = 1;
+        std::vector<int32_t> all;
+        for (int id : {x, y, w}) for (int32_t l : labs[id]) if (std::find(all.begin(), all.end(), l) == all.end()) all.push_back(l);
+        for (int32_t l : all) {
+          const bool inA = has(x, l) || has(y, l), inB = has(w, l), inC = has(out, l);
+          if (!inC) K *= ext(l);
+          else if (inA && !inB) M *= ext(l);
+          else if (inB && !inA) N *= ext(l);
+        }
+        return M >= 64 && N >= 32 && K >= 8 && M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31);
+      };
+      for (int s1 = 0; s1 + 1 < d.n_steps; ++s1) {
+        const int t1 = d.n_inputs + s1, p = d.step_lhs[s1], q = d.step_rhs[s1];
+        const int s2 = consumer[t1];
+        if (q < 0 || p < 0 || s2 < 0 || absorbed[s1] || fuse[s1].x >= 0 || fuse[s2].x >= 0) continue;
+        const int other = d.step_lhs[s2] == t1 ? d.step_rhs[s2] : d.step_lhs[s2];
+        if (other < 0 || !distinct(p) || !distinct(q) || !distinct(other) || !distinct(t1)) continue;
+        const int out2 = d.n_inputs + s2;
+        bool summed1 = false;          // does s1 sum anything?
+        for (int id : {p, q}) for (int32_t l : labs[id]) if (!has(t1, l)) summed1 = true;
+        if (!summed1) {
+          // pattern A: t1 = p (.) q element-wise, consumed by a GEMM with `other`
+          bool k2 = false;
+          for (int id : {t1, other}) for (int32_t l : labs[id]) if (!has(out2, l)) k2 = true;
+          const bool big = numel[t1] >= (double)(1 << 20) && numel[t1] >= 8.0 * (numel[p] + numel[q]);
+          if (k2 && gemm_ok(p, q, other, out2) && (fmode == 1 || big)) {
+            // X = the factor with the larger stride pattern first is irrelevant: keep (p, q)
+            fuse[s2].x = p; fuse[s2].y = q; fuse[s2].w = other; absorbed[s1] = 1;
+          }
+        } else {
+          // pattern B: t1 = p . q (a GEMM), then re-weighted / summed by `other` whose labels all live in t1
+          bool sub = true;
+          for (int32_t l : labs[other]) if (!has(t1, l)) sub = false;
+          if (!sub) continue;
+          const bool big = numel[t1] >= (double)(1 << 20) && numel[t1] >= 4.0 * numel[out2] && numel[other] * 16.0 <= numel[t1];
+          if (!(fmode == 1 || big)) continue;
+          // `other` joins the side that carries more of its kept labels
+          int kp = 0, kq = 0;
+          for (int32_t l : labs[other]) if (has(out2, l)) { kp += has(p, l); kq += has(q, l); }
+          int x = kp >= kq ? p : q, w = kp >= kq ? q : p;
+          if (!gemm_ok(x, other, w, out2)) { std::swap(x, w); if (!gemm_ok(x, other, w, out2)) continue; }
+          fuse[s2].x = x; fuse[s2].y = other; fuse[s2].w = w; absorbed[s1] = 1;
+        }
+      }
+    }
+  }
+
   // ---- steps ----------------------------------------------------------------
   std::vector<int> consumed(d.n_inputs + d.n_steps, 0);
   Arena arena;
@@ -174,13 +269,37 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     std::vector<int32_t> out_labels(d.step_out_labels + out_cur, d.step_out_labels + out_cur + ond);
     out_cur += ond;
 
+    if (absorbed[s]) {
+      // this step's product is formed on the fly inside the step that consumes it: no kernel, no buffer; its
+      // operands stay alive until that step has read them
+      Tensor vt;
+      vt.producer = s;
+      vt.labels = out_labels;
+      for (int32_t lab : out_labels) {
+        auto it = label_ext.find(lab);
+        if (it == label_ext.end()) { err = fmt("step %lld: output label %lld is in neither operand", s, lab); return CTN_INVALID_ARG; }
+        vt.dims.push_back(it->second);
+        vt.numel *= it->second;
+      }
+      vt.strides.assign(vt.labels.size(), 0);
+      st.lhs = lhs; st.rhs = rhs; st.out = out_id;
+      st.kernel = CTN_KERNEL_FUSED;
+      st.Bt = st.M = st.N = st.K = 0;
+      st.blocks = 0; st.partials = 0; st.flops = 0; st.chain_ok = false;
+      P.tensors.push_back(std::move(vt));
+      P.steps.push_back(std::move(st));
+      continue;
+    }
+    const bool fused = fuse[s].x >= 0;
+    if (fused) { lhs = fuse[s].x; rhs = fuse[s].w; }   // A = X (.) Y (Y = fuse[s].y), B = W
+
     // -- label census
     std::vector<LabelInfo> info;
     auto find = [&](int32_t lab) -> LabelInfo* {
       for (auto& l : info) if (l.label == lab) return &l;
       return nullptr;
     };
-    auto scan = [&](const Tensor& T, bool isA) {
+    auto scan = [&](const Tensor& T, int which /*0 A (X), 1 B, 2 second A-side tensor Y*/) {
       for (size_t a = 0; a < T.labels.size(); ++a) {
         LabelInfo* l = find(T.labels[a]);
         if (!l) {
@@ -190,12 +309,15 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
           l->ext = T.dims[a];
           l->firstPos = (int)info.size();
         }
-        (isA ? l->sA : l->sB) += T.strides[a];  // repeated label = diagonal: strides add
-        (isA ? l->inA : l->inB) = true;
+        (which == 0 ? l->sA : which == 1 ? l->sB : l->sA2) += T.strides[a];  // repeated label = diagonal: strides add
+        if (which == 1) l->inB = true; else l->inA = true;
+        if (which == 0) l->inX = true;
+        if (which == 2) l->inA2 = true;
       }
     };
-    scan(P.tensors[lhs], true);
-    if (rhs >= 0) scan(P.tensors[rhs], false);
+    scan(P.tensors[lhs], 0);
+    if (fused) scan(P.tensors[fuse[s].y], 2);
+    if (rhs >= 0) scan(P.tensors[rhs], 1);
     for (size_t a = 0; a < out_labels.size(); ++a) {
       LabelInfo* l = find(out_labels[a]);
       if (!l) { err = fmt("step %lld: output label %lld is in neither operand", s, out_labels[a]); return CTN_INVALID_ARG; }
@@ -205,7 +327,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
 
     // -- operand swap: the output's unit-stride label should be a column (N) label
     bool swap = false;
-    if (rhs >= 0) {
+    if (rhs >= 0 && !fused) {   // (the on-the-fly product can only be the A operand)
       if (last) {
         if (!out_labels.empty()) {
           LabelInfo* l = find(out_labels.back());
@@ -222,6 +344,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       for (auto& l : info) { std::swap(l.sA, l.sB); std::swap(l.inA, l.inB); }
     }
     st.lhs = lhs; st.rhs = rhs; st.out = out_id; st.swapped = swap;
+    st.lhs2 = fused ? fuse[s].y : -1;
 
     // -- classify and order
     std::vector<LabelInfo*> G[4];
@@ -232,8 +355,8 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     auto by = [](bool useA) {
       return [useA](const LabelInfo* x, const LabelInfo* y) {
         // labels absent from the ordering operand (summed out of the other one) go outermost
-        int64_t sx = useA ? (x->inA ? x->sA : INT64_MAX) : (x->inB ? x->sB : INT64_MAX);
-        int64_t sy = useA ? (y->inA ? y->sA : INT64_MAX) : (y->inB ? y->sB : INT64_MAX);
+        int64_t sx = useA ? (x->inA ? std::max(x->sA, x->sA2) : INT64_MAX) : (x->inB ? x->sB : INT64_MAX);
+        int64_t sy = useA ? (y->inA ? std::max(y->sA, y->sA2) : INT64_MAX) : (y->inB ? y->sB : INT64_MAX);
         if (sx != sy) return sx > sy;  // descending stride: last label is the most contiguous
         return x->firstPos < y->firstPos;
       };
@@ -290,7 +413,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       }
       return 0;
     };
-    st.modeA = mode_of(true);
+    st.modeA = fused ? 3 : mode_of(true);   // 3 = element-wise product of two tensors formed while staging (KR loader)
     st.modeB = rhs >= 0 ? mode_of(false) : 0;
     if (!G[kN].empty()) {
       const LabelInfo* u = G[kN].back();
@@ -323,7 +446,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       // blocks / partial slots stay counted in 128 x 128 units.
       const int64_t pad128 = round_up(st.M, kTileM) * round_up(st.N, kTileN);
       const int64_t pad256 = round_up(st.M, 256) * round_up(st.N, kTileN);
-      if (st.modeA >= 1 && st.modeB >= 1 && st.tileN == kTileN && st.cvec && st.K >= 32 &&
+      if (!fused && st.modeA >= 1 && st.modeB >= 1 && st.tileN == kTileN && st.cvec && st.K >= 32 &&
           st.M > kTileM && pad256 * 100 <= pad128 * 115 &&
           st.rhs >= 0 && P.tensors[st.lhs].numel <= (1LL << 30) && P.tensors[st.rhs].numel <= (1LL << 30)) {  // 32-bit byte offsets
         st.tileM = 256;
@@ -417,7 +540,8 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     // (x2: the launcher may halve the column tile of an under-filled fp32 MFMA launch)
     if (st.collapse) P.max_collapse_blocks = std::max<int64_t>(P.max_collapse_blocks, 2 * (int64_t)st.blocks);
     st.flops = (st.has_k ? 2.0 : 1.0) * (double)st.Bt * (double)st.M * (double)st.N * (double)st.K +
-               (P.stabilize ? 3.0 * (double)out.numel : 0.0);
+               (P.stabilize ? 3.0 * (double)out.numel : 0.0) +
+               (fused ? (double)st.Bt * (double)st.M * (double)st.K : 0.0);   // the multiplies of the fused product
     P.flops += st.flops;
 
     // -- gather-offset tables
@@ -437,10 +561,15 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     }
     build_table(gk, 0, padK, tb);  st.t.okA = append(P.tables, tb);
     build_table(gk, 1, padK, tb);  st.t.okB = append(P.tables, tb);
+    if (fused) {   // the second tensor of the A side (a label it does not carry has stride 0)
+      build_table(gb, 3, st.Bt, tb); st.t.obA2 = append(P.tables, tb);
+      build_table(gm, 3, padM, tb);  st.t.omA2 = append(P.tables, tb);
+      build_table(gk, 3, padK, tb);  st.t.okA2 = append(P.tables, tb);
+    }
 
     // -- workspace: allocate the output, then release the consumed intermediates
     if (!last) out.ws_offset = arena.alloc(out.numel * es);
-    for (int id : {lhs, rhs}) {
+    for (int id : {lhs, rhs, st.lhs2}) {
       if (id >= d.n_inputs) arena.release(P.tensors[id].ws_offset, P.tensors[id].numel * es);
     }
     P.tensors.push_back(std::move(out));

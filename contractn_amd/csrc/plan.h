@@ -43,11 +43,13 @@ struct Tensor {
 // offsets (in int32 entries) of one step's tables inside Plan::tables
 struct TableRefs {
   int64_t obA = 0, obB = 0, obC = 0, omA = 0, omC = 0, onB = 0, onC = 0, okA = 0, okB = 0;
+  int64_t obA2 = 0, omA2 = 0, okA2 = 0;  // fused steps (modeA == 3): the second tensor of the A side
   int64_t ohA = 0, ohB = 0, ohC = 0, olA = 0, olB = 0, olC = 0;  // streaming kernels: (hi, lo) output groups
 };
 
 struct Step {
   int lhs = -1, rhs = -1, out = -1;  // tensor ids after the optional operand swap; rhs -1 = unary
+  int lhs2 = -1;         // fused steps: A = tensors[lhs] (.) tensors[lhs2], formed on the fly (mode 3)
   bool swapped = false;
   int kernel = CTN_KERNEL_ELEMENT;
   int64_t Bt = 1, M = 1, N = 1, K = 1;

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("CTN_LIB_PATH") or os.path.join(_HERE, "lib", "libctn_
 
 CTN_F32, CTN_F64 = 0, 1
 CTN_MEM_HOST, CTN_MEM_DEVICE = 0, 1
-KERNEL_NAMES = {0: "element", 1: "dot", 2: "mfma_f32", 3: "mfma_f64", 4: "rowdot"}
+KERNEL_NAMES = {0: "element", 1: "dot", 2: "mfma_f32", 3: "mfma_f64", 4: "rowdot", 5: "fused"}
 
 _STATUS_EXC = {
     -1: AssertionError,

@@ -63,8 +63,12 @@ typedef enum {
                              64x64 split-K form when a launch cannot fill the chip */
   CTN_KERNEL_MFMA_F64 = 3,/* 128x64 LDS-tiled v_mfma_f64_16x16x4_f64 GEMM, gather loads; 128x128 tiles fed by
                              LDS-DMA (tile_n = 128); 64x64 split-K form for small launches */
-  CTN_KERNEL_ROWDOT = 4   /* one wave per output element, lanes along a unit-stride K (GEMV-like); K split over
+  CTN_KERNEL_ROWDOT = 4,  /* one wave per output element, lanes along a unit-stride K (GEMV-like); K split over
                              workgroups as well when the outputs are few */
+  CTN_KERNEL_FUSED = 5    /* no kernel: the step's result is formed on the fly inside the step that consumes it - an
+                             element-wise (Khatri-Rao / Hadamard / broadcast) product as the A operand of an MFMA GEMM
+                             (that step reports mode_a = 3), or a GEMM whose small re-weighting consumer was regrouped
+                             into it; the intermediate never exists and its rescale is reported as 0.0 */
 } ctn_kernel_kind;
 
 typedef struct ctn_plan ctn_plan;
@@ -96,7 +100,8 @@ typedef struct {
   int32_t swapped;     /* 1 if the engine exchanged lhs/rhs so that the output's unit-stride label is a column label */
   int64_t batch;       /* |B|: labels shared by both operands and kept (hyperedge / batch) */
   int64_t m, n, k;     /* |M|, |N| free extents, |K| contracted extent (incl. summed-out labels) */
-  int32_t mode_a;      /* 0 gather, 1 vector loads along the free index, 2 vector loads along k */
+  int32_t mode_a;      /* 0 gather, 1 vector loads along the free index, 2 vector loads along k,
+                          3 element-wise product of two tensors formed while the tile is staged (fused step) */
   int32_t mode_b;
   int32_t partials;    /* abs-sum partials per replica written by the step (<= 1024; more workgroups are collapsed to 1) */
   int32_t blocks;      /* workgroups per replica */

@@ -685,3 +685,82 @@ def test_underflowing_network_matches_the_reference_zero():
     g = load_golden("mps_overlap_4x32x4_f32_tiny")
     t, c = contract(g["einsum_str"], *g["operands"], optimize=g["path"], split_format=True)
     assert float(t) == 0.0 == float(g["t_hat"]) and float(c) == 0.0 == float(g["log_scale"])
+
+
+# ---- fused steps: an element-wise product formed on the fly as the A operand of the GEMM that consumes it -----------
+@pytest.fixture
+def force_fusion(monkeypatch):
+    """The planner fuses only where the intermediate is large (>= 2^20 elements); these tests force it on small
+    networks (CTN_FUSE is read when a plan is created, so the plan cache is cleared around them)."""
+    monkeypatch.setenv("CTN_FUSE", "1")
+    E.clear_caches()
+    yield
+    E.clear_caches()
+
+
+def _fused_infos(einstr, shapes, path):
+    clist = E._contract_path(einstr, tuple(tuple(s) for s in shapes), optimize=path, memory_limit=None, use_blas=True)
+    return E._native_plan(clist, tuple(tuple(s) for s in shapes), "float32").step_infos()
+
+
+@pytest.mark.parametrize("einstr,shapes,path", [
+    ("ac,ad,ae->cde", [(48, 40), (48, 36), (48, 44)], ((0, 1), (0, 1))),          # CP: Khatri-Rao then GEMM (pattern A)
+    ("ac,ad,ae->cde", [(130, 33), (130, 20), (130, 70)], ((0, 1), (0, 1))),       # ragged everything, K = 130
+    ("xac,xad,xae->xcde", [(2, 64, 16), (2, 64, 24), (2, 64, 40)], ((0, 1), (0, 1))),  # a batch label through all three
+    ("ac,ad,ae->edc", [(64, 32), (64, 16), (64, 48)], ((0, 1), (0, 1))),          # last step with M innermost in the output
+    ("m,mk,kn->mn", [(256,), (256, 64), (64, 96)], ((0, 1), (0, 1))),             # a vector scaling the rows (Hadamard, pattern A)
+])
+def test_fused_product_as_gemm_operand_vs_numpy(einstr, shapes, path, force_fusion):
+    rng = np.random.default_rng(17)
+    ops = [(rng.standard_normal(s) * rng.uniform(0.5, 2.0)).astype(np.float32) for s in shapes]
+    infos = _fused_infos(einstr, shapes, path)
+    assert [i["kernel"] for i in infos] == [5, 2] and infos[1]["mode_a"] == 3, infos
+    t_hat, c = contract(einstr, *ops, optimize=path, split_format=True)
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    got = t_hat.astype(np.float64) * np.exp(float(c))
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 2e-4 * np.max(np.abs(ref))
+    assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-5
+
+
+def test_fused_gemm_with_reweighting_consumer_batched_mps(force_fusion):
+    """Pattern B: an MPS site applied to a batch of inputs - `bl,plr->bpr` then `bpr,bp->br` - runs as ONE GEMM over
+    (p, l) whose A operand v[b,l] * x[b,p] is formed on the fly; v is a rescaled intermediate of the previous site.
+    Against the oracle on the same path (the oracle materialises every intermediate)."""
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from oracle import cpu_ref
+    from tests import networks as nets
+
+    B, n_sites, bond, phys = 256, 6, 64, 4
+    tn, inputs = nets.batched_mps(TN, n_sites, bond, phys, B, dtype=np.float32, seed=4)
+    path = ssa_to_linear(nets.batched_mps_path(n_sites), 2 * n_sites)
+    ops = E.make_arg_packer(tn)(tn.params, inputs)
+    shapes = [o.shape for o in ops]
+    infos = _fused_infos(tn.einsum_str, shapes, path)
+    assert sum(i["kernel"] == 5 for i in infos) == n_sites - 2 and sum(i["mode_a"] == 3 for i in infos) == n_sites - 2
+    assert max(i["out_numel"] for i in infos if i["kernel"] != 5) <= B * bond      # the B x phys x bond tensor never exists
+    fun = tn.make_contract_fun(optimize=path, split_format=True)
+    t, c = fun(tn.params, inputs)
+    clist = E._contract_path(tn.einsum_str, tuple(shapes), optimize=path, memory_limit=None, use_blas=True)
+    rt, rc, _ = cpu_ref.core_contract(list(ops), clist)
+    got = t.astype(np.float64) * np.exp(float(c))
+    ref = np.asarray(rt, dtype=np.float64) * np.exp(float(rc))
+    assert np.max(np.abs(got - ref)) <= 1e-3 * np.max(np.abs(ref))
+    # replicas in flight and the unfused plan give the same numbers to rounding
+    t2, c2 = fun(tn.params, inputs)
+    assert np.array_equal(t2, t) and float(c2) == float(c)
+
+
+def test_fusion_is_off_for_small_intermediates_and_switchable(monkeypatch):
+    monkeypatch.delenv("CTN_FUSE", raising=False)
+    E.clear_caches()
+    small = _fused_infos("ac,ad,ae->cde", [(48, 40), (48, 36), (48, 44)], ((0, 1), (0, 1)))
+    assert all(i["kernel"] != 5 for i in small)                               # 69k-element product: kept as a step
+    big = _fused_infos("ac,ad,ae->cde", [(256, 256), (256, 128), (256, 64)], ((0, 1), (0, 1)))
+    assert [i["kernel"] for i in big] == [5, 2]                              # 8.4M-element product: fused by default
+    monkeypatch.setenv("CTN_FUSE", "0")
+    E.clear_caches()
+    off = _fused_infos("ac,ad,ae->cde", [(256, 256), (256, 128), (256, 64)], ((0, 1), (0, 1)))
+    assert all(i["kernel"] != 5 for i in off)
+    E.clear_caches()
