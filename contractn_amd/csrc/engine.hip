@@ -178,6 +178,8 @@ static void launch_mfma_a(int ma, int mb, dim3 grid, hipStream_t st, const StepA
     case 1: launch_mfma_b<1, BK, TN, TM>(mb, grid, st, a); break;
     case 2: launch_mfma_b<2, BK, TN, TM>(mb, grid, st, a); break;
     case 3: launch_mfma_b<3, BK, TN, TM>(mb, grid, st, a); break;   // A = X (.) Y formed while staging (fused step)
+    case 4: launch_mfma_b<4, BK, TN, TM>(mb, grid, st, a); break;   // ... with 16-byte accesses along the rows
+    case 5: launch_mfma_b<5, BK, TN, TM>(mb, grid, st, a); break;   // ... along k
     default: launch_mfma_b<0, BK, TN, TM>(mb, grid, st, a); break;
   }
 }
@@ -212,7 +214,7 @@ static void launch_mfma(int ma, int mb, int tile_m, int tile_n, dim3 grid, hipSt
 static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
   const int mode = sw.splitk;
   const bool mfma = (dtype == CTN_F32 && st.kernel == CTN_KERNEL_MFMA_F32) || (dtype == CTN_F64 && st.kernel == CTN_KERNEL_MFMA_F64);
-  if (mode == 0 || !mfma || st.collapse || st.K < 128 || st.modeA == 3) return 0;
+  if (mode == 0 || !mfma || st.collapse || st.K < 128 || st.modeA >= 3) return 0;
   const int max_tiles = sw.splitk_max;
   const int64_t limit = max_tiles > 0 ? max_tiles : n_cu / 2;
   if (mode != 1 && (int64_t)st.blocks * R > limit) return 0;
@@ -229,7 +231,7 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSw
 // 16 x 16: on 64 tiles of 32 x 32 three quarters of the matrix pipes idle and the step takes 14 us instead of ~6);
 // at most kMaxPartials tiles per replica (one abs-sum partial each), both k-offset tables in LDS.
 static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
-  if (sw.lat == 0 || dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.rhs < 0 || st.modeA == 3) return 0;
+  if (sw.lat == 0 || dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.rhs < 0 || st.modeA >= 3) return 0;
   if (st.K > kLatMaxK || st.K < 32) return 0;
   if (sw.lat != 1 && ((int64_t)st.blocks * R > n_cu / 2 || st.K < 128)) return 0;
   auto tiles = [&](int T) { return st.Bt * ((st.M + T - 1) / T) * ((st.N + T - 1) / T); };
@@ -391,6 +393,7 @@ static int exec_launch_steps(Exec* E) {
     part_of(st.lhs2, &a.partA2, &a.PA2, &a.strideA2, &a.numelA2);
     a.obA2 = T + st.t.obA2; a.omA2 = T + st.t.omA2; a.okA2 = T + st.t.okA2;
     a.idA2 = st.lhs2 >= 0 ? st.lhs2 : E->n_tensors - 1;
+    a.krX = st.krX; a.krY = st.krY;
     double* part_dst = E->d_partials + (size_t)E->step_off[s] * R;
     const int part_stride = E->step_partials[s];    // slots per replica of this step's region
     a.partC = st.collapse ? E->d_scratch : part_dst;
@@ -929,6 +932,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   for (int s = 0; s < P.n_steps; ++s) {
     const Step& st = P.steps[s];
     E.step_partials[s] = std::max(st.partials, 1);
+    if (P.chain) { E.step_off[s] = E.part_slots++; continue; }   // the chain walker: one slot per step, whatever the kernel kind
     if (const int T = lat_form(st, replicas, E.n_cu, P.dtype, E.sw))
       E.step_partials[s] = (int)(st.Bt * ((st.M + T - 1) / T) * ((st.N + T - 1) / T));
     else if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||

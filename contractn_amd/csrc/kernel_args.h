@@ -66,6 +66,7 @@ struct StepArgs {
   const double* partA2;
   double numelA2;
   int32_t idA2, PA2, strideA2;
+  int32_t krX, krY;   // modes 4 / 5: how each factor is read along the vector direction (0 gather, 1 float4, 2 broadcast)
 };
 
 struct FinalArgs {

@@ -193,10 +193,120 @@ struct TileLoaderKR {
   static __device__ __forceinline__ int idx(int row, int k) { return k * ROWS + row; }
 };
 
+// MODES 4 / 5: the same on-the-fly product with 16-byte accesses where the factors allow it.  Along the vector
+// direction - 4 consecutive rows (mode 4, LDS image [k][rows] like mode 1) or 4 consecutive k (mode 5, image
+// [rows][BK+1] like mode 2) - each factor is, by its stride along the innermost label there: contiguous (kind 1: one
+// float4 load), constant (kind 2: one scalar, broadcast - the factor does not carry that label), or anything else
+// (kind 0: four scalar gathers).  The planner picks the direction in which at least one factor is contiguous and
+// passes the kinds (StepArgs::krX / krY); they are wave-uniform, so the branches cost nothing.
+//   CP   `ad,ac->acd . ae`: rows (c, d), d innermost: B[a, d] contiguous, A[a, c] constant        -> mode 4
+//   MPS  `bl (.) bp . plr`: k = (p, l), l innermost: v[b, l] contiguous, x[b, p] constant          -> mode 5
+template <int DIR, int BK, int ROWS>
+struct TileLoaderKRV {
+  static_assert(DIR == 1 || DIR == 2, "vector direction");
+  static constexpr int NV = ROWS * BK / 256;               // floats staged per thread
+  static constexpr int VPR = ROWS / 4;                     // DIR 1: float4 per k-row
+  static constexpr int RPP = 256 / VPR;                    // DIR 1: k-rows covered per pass
+  static constexpr int NT = DIR == 1 ? BK / RPP : 1;       // k-table positions per thread and tile
+  static constexpr int NM = DIR == 2 ? NV / 4 : 1;         // row positions per thread
+  static constexpr int LDK = BK + 1;
+  static constexpr int kSize = DIR == 2 ? ROWS * LDK : BK * ROWS;
+  float v[NV];
+  // offsets of the 4 elements of a vector differ only for a gathered factor; [.][0] serves kinds 1 and 2
+  int kx[NT][DIR == 2 ? 4 : 1], ky[NT][DIR == 2 ? 4 : 1];   // k-table entries of the NEXT tile
+  int mx[NM][DIR == 1 ? 4 : 1], my[NM][DIR == 1 ? 4 : 1];   // row-table entries
+  bool okm[NM];
+  int kindX, kindY;
+  const int32_t* __restrict__ ok2;
+  const float* __restrict__ base2;
+
+  __device__ __forceinline__ void init(const int32_t* __restrict__ om, int m0, int M, int tid) {
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      const int gm = DIR == 1 ? m0 + (tid % VPR) * 4 : m0 + ((tid + i * 256) / (BK / 4));
+#pragma unroll
+      for (int j = 0; j < (DIR == 1 ? 4 : 1); ++j) mx[i][j] = om[gm + j];
+      okm[i] = gm < M;
+    }
+  }
+  __device__ __forceinline__ void init2(const int32_t* __restrict__ om2, const int32_t* __restrict__ ok2_,
+                                        const float* __restrict__ base2_, int m0, int tid, int kx_, int ky_) {
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      const int gm = DIR == 1 ? m0 + (tid % VPR) * 4 : m0 + ((tid + i * 256) / (BK / 4));
+#pragma unroll
+      for (int j = 0; j < (DIR == 1 ? 4 : 1); ++j) my[i][j] = om2[gm + j];
+    }
+    ok2 = ok2_;
+    base2 = base2_;
+    kindX = kx_;
+    kindY = ky_;
+  }
+  __device__ __forceinline__ void tab(const int32_t* __restrict__ ok, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int kk = DIR == 1 ? k0 + tid / VPR + RPP * i : k0 + (tid % (BK / 4)) * 4;
+#pragma unroll
+      for (int j = 0; j < (DIR == 2 ? 4 : 1); ++j) { kx[i][j] = ok[kk + j]; ky[i][j] = ok2[kk + j]; }
+    }
+  }
+  // four values of one factor: rows gm..gm+3 at one k (DIR 1) or k..k+3 of one row (DIR 2)
+  template <typename OM, typename OK>
+  static __device__ __forceinline__ void four(const float* __restrict__ base, int kind, const OM& om, const OK& ok, float (&o)[4]) {
+    if (kind == 1) {
+      const float4 x = *reinterpret_cast<const float4*>(base + om[0] + ok[0]);
+      o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w;
+    } else if (kind == 2) {
+      const float x = base[om[0] + ok[0]];
+      o[0] = o[1] = o[2] = o[3] = x;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = base[om[DIR == 1 ? j : 0] + ok[DIR == 2 ? j : 0]];
+    }
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ base) {
+    constexpr int N = DIR == 1 ? NT : NM;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float a[4], b[4];
+      four(base, kindX, mx[DIR == 1 ? 0 : i], kx[DIR == 1 ? i : 0], a);
+      four(base2, kindY, my[DIR == 1 ? 0 : i], ky[DIR == 1 ? i : 0], b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * i + j] = a[j] * b[j];
+    }
+  }
+  template <bool FULL>
+  __device__ __forceinline__ void store(float* __restrict__ s, int k0, int K, int tid) const {
+    if (DIR == 1) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int kr = tid / VPR + RPP * i;
+        const bool in = FULL || (okm[0] && (k0 + kr) < K);
+        *reinterpret_cast<float4*>(s + kr * ROWS + (tid % VPR) * 4) =
+            make_float4(in ? v[4 * i] : 0.f, in ? v[4 * i + 1] : 0.f, in ? v[4 * i + 2] : 0.f, in ? v[4 * i + 3] : 0.f);
+      }
+    } else {
+      const bool kin = (k0 + (tid % (BK / 4)) * 4) < K;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const bool in = FULL || (okm[i] && kin);
+        float* d = s + ((tid + i * 256) / (BK / 4)) * LDK + (tid % (BK / 4)) * 4;
+        d[0] = in ? v[4 * i] : 0.f; d[1] = in ? v[4 * i + 1] : 0.f;
+        d[2] = in ? v[4 * i + 2] : 0.f; d[3] = in ? v[4 * i + 3] : 0.f;
+      }
+    }
+  }
+  static __device__ __forceinline__ int idx(int row, int k) { return DIR == 2 ? row * LDK + k : k * ROWS + row; }
+};
+
 template <int MODE, int BK, int ROWS>
 struct LoaderOf { typedef TileLoader<MODE, BK, ROWS> type; };
 template <int BK, int ROWS>
 struct LoaderOf<3, BK, ROWS> { typedef TileLoaderKR<BK, ROWS> type; };
+template <int BK, int ROWS>
+struct LoaderOf<4, BK, ROWS> { typedef TileLoaderKRV<1, BK, ROWS> type; };
+template <int BK, int ROWS>
+struct LoaderOf<5, BK, ROWS> { typedef TileLoaderKRV<2, BK, ROWS> type; };
 
 template <int MA, int MB, int BK, int TN, bool FULL, int BM>
 __device__ __forceinline__ void mfma_mainloop(typename LoaderOf<MA, BK, BM>::type& la, TileLoader<MB, BK, TN>& lb,
@@ -234,7 +344,7 @@ __device__ __forceinline__ void mfma_mainloop(typename LoaderOf<MA, BK, BM>::typ
   int fbx[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) fbx[j] = LB::idx(wn + j * 32 + l31, h);
-  constexpr int stepA = MA == 2 ? 2 : 2 * BM;  // advance of the fragment index per k-step (k += 2); KR: [k][rows] like mode 0
+  constexpr int stepA = (MA == 2 || MA == 5) ? 2 : 2 * BM;  // advance of the fragment index per k-step (k += 2)
   constexpr int stepB = MB == 2 ? 2 : 2 * TN;
 
   for (int kt = 0; kt < nkt; ++kt) {
@@ -321,7 +431,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   float scA = producer_scale<float>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
   const float scB = producer_scale<float>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
   float scA2 = 1.f;
-  if constexpr (MA == 3) scA2 = producer_scale<float>(a.partA2, a.PA2, a.strideA2, a.numelA2, a.min_norm, r);
+  if constexpr (MA >= 3) scA2 = producer_scale<float>(a.partA2, a.PA2, a.strideA2, a.numelA2, a.min_norm, r);
 
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
@@ -335,6 +445,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   LB lb;
   la.init(a.omA, m0, a.M, tid);
   if constexpr (MA == 3) la.init2(a.omA2, a.okA2, (const float*)tp[a.idA2] + a.obA2[b], m0, tid);
+  if constexpr (MA >= 4) la.init2(a.omA2, a.okA2, (const float*)tp[a.idA2] + a.obA2[b], m0, tid, a.krX, a.krY);
   lb.init(a.onB, n0, a.N, tid);
 
   const int lane = tid & 63, w = tid >> 6;
@@ -364,7 +475,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
 
   // epilogue: lazy rescale, store through the C offset tables, abs-sum partial
   // (KR: both factors of the A operand carry a rescale; folded into one multiplier)
-  const float iA = MA == 3 ? (1.0f / scA) * (1.0f / scA2) : 1.0f / scA, iB = 1.0f / scB;
+  const float iA = MA >= 3 ? (1.0f / scA) * (1.0f / scA2) : 1.0f / scA, iB = 1.0f / scB;
   float asum = 0.f;
   {
     // Each WAVE stages its own 64 x TN/2 accumulator block through its quarter of the (now idle)

@@ -414,6 +414,25 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       return 0;
     };
     st.modeA = fused ? 3 : mode_of(true);   // 3 = element-wise product of two tensors formed while staging (KR loader)
+    if (fused) {
+      // 16-byte accesses where the factors allow it: along 4 consecutive rows (mode 4) or 4 consecutive k (mode 5) a
+      // factor is contiguous (1), constant (2: it does not carry the innermost label there) or gathered (0)
+      auto kind_along = [&](const LabelInfo* l, bool isX) -> int {
+        const bool present = isX ? l->inX : l->inA2;
+        const int64_t stride = isX ? l->sA : l->sA2;
+        if (!present || stride == 0) return 2;
+        if (stride != 1) return 0;
+        for (auto& o : info)
+          if (&o != l && (isX ? o.inX : o.inA2) && (isX ? o.sA : o.sA2) % vec != 0) return 0;
+        return 1;
+      };
+      for (int dir = 1; dir <= 2 && st.modeA == 3; ++dir) {
+        const auto& grp = dir == 1 ? G[kM] : G[kK];
+        if (grp.empty() || grp.back()->ext % vec != 0) continue;
+        const int kx = kind_along(grp.back(), true), ky = kind_along(grp.back(), false);
+        if (kx == 1 || ky == 1) { st.modeA = 3 + dir; st.krX = kx; st.krY = ky; }
+      }
+    }
     st.modeB = rhs >= 0 ? mode_of(false) : 0;
     if (!G[kN].empty()) {
       const LabelInfo* u = G[kN].back();

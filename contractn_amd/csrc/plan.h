@@ -49,7 +49,8 @@ struct TableRefs {
 
 struct Step {
   int lhs = -1, rhs = -1, out = -1;  // tensor ids after the optional operand swap; rhs -1 = unary
-  int lhs2 = -1;         // fused steps: A = tensors[lhs] (.) tensors[lhs2], formed on the fly (mode 3)
+  int lhs2 = -1;         // fused steps: A = tensors[lhs] (.) tensors[lhs2], formed on the fly (modeA 3, 4, 5)
+  int krX = 0, krY = 0;  // modeA 4 / 5: how each factor is read along the vector direction (0 gather, 1 float4, 2 broadcast)
   bool swapped = false;
   int kernel = CTN_KERNEL_ELEMENT;
   int64_t Bt = 1, M = 1, N = 1, K = 1;

@@ -67,7 +67,7 @@ typedef enum {
                              workgroups as well when the outputs are few */
   CTN_KERNEL_FUSED = 5    /* no kernel: the step's result is formed on the fly inside the step that consumes it - an
                              element-wise (Khatri-Rao / Hadamard / broadcast) product as the A operand of an MFMA GEMM
-                             (that step reports mode_a = 3), or a GEMM whose small re-weighting consumer was regrouped
+                             (that step reports mode_a >= 3), or a GEMM whose small re-weighting consumer was regrouped
                              into it; the intermediate never exists and its rescale is reported as 0.0 */
 } ctn_kernel_kind;
 
@@ -101,7 +101,8 @@ typedef struct {
   int64_t batch;       /* |B|: labels shared by both operands and kept (hyperedge / batch) */
   int64_t m, n, k;     /* |M|, |N| free extents, |K| contracted extent (incl. summed-out labels) */
   int32_t mode_a;      /* 0 gather, 1 vector loads along the free index, 2 vector loads along k,
-                          3 element-wise product of two tensors formed while the tile is staged (fused step) */
+                          3 / 4 / 5 element-wise product of two tensors formed while the tile is staged (fused
+                          step): scalar gathers / 16-byte accesses along the rows / along k */
   int32_t mode_b;
   int32_t partials;    /* abs-sum partials per replica written by the step (<= 1024; more workgroups are collapsed to 1) */
   int32_t blocks;      /* workgroups per replica */

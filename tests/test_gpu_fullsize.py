@@ -91,7 +91,7 @@ def test_cfg4_cp_wide_r4096_runs_without_its_2_to_the_32_element_intermediate():
     A, B, C = _mats(3, r, n, seed=9, scale=64.0)
     clist = E_._contract_path("ac,ad,ae->cde", ((r, n),) * 3, optimize="auto", memory_limit=None, use_blas=True)
     infos = E_._native_plan(clist, ((r, n),) * 3, "float32").step_infos()
-    assert [i["kernel"] for i in infos] == [5, 2] and infos[1]["mode_a"] == 3 and infos[1]["k"] == r
+    assert [i["kernel"] for i in infos] == [5, 2] and infos[1]["mode_a"] >= 3 and infos[1]["k"] == r
     t, c = contract("ac,ad,ae->cde", A, B, C, split_format=True)
     scale = float(torch.exp(c.double()))
     peak = float(t.abs().max()) * scale

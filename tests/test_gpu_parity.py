@@ -714,7 +714,7 @@ def test_fused_product_as_gemm_operand_vs_numpy(einstr, shapes, path, force_fusi
     rng = np.random.default_rng(17)
     ops = [(rng.standard_normal(s) * rng.uniform(0.5, 2.0)).astype(np.float32) for s in shapes]
     infos = _fused_infos(einstr, shapes, path)
-    assert [i["kernel"] for i in infos] == [5, 2] and infos[1]["mode_a"] == 3, infos
+    assert [i["kernel"] for i in infos] == [5, 2] and infos[1]["mode_a"] >= 3, infos
     t_hat, c = contract(einstr, *ops, optimize=path, split_format=True)
     ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
     got = t_hat.astype(np.float64) * np.exp(float(c))
@@ -738,7 +738,7 @@ def test_fused_gemm_with_reweighting_consumer_batched_mps(force_fusion):
     ops = E.make_arg_packer(tn)(tn.params, inputs)
     shapes = [o.shape for o in ops]
     infos = _fused_infos(tn.einsum_str, shapes, path)
-    assert sum(i["kernel"] == 5 for i in infos) == n_sites - 2 and sum(i["mode_a"] == 3 for i in infos) == n_sites - 2
+    assert sum(i["kernel"] == 5 for i in infos) == n_sites - 2 and sum(i["mode_a"] >= 3 for i in infos) == n_sites - 2
     assert max(i["out_numel"] for i in infos if i["kernel"] != 5) <= B * bond      # the B x phys x bond tensor never exists
     fun = tn.make_contract_fun(optimize=path, split_format=True)
     t, c = fun(tn.params, inputs)
