@@ -158,6 +158,11 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
   // site applied to a batch of inputs, reference paper Fig. 1d) is the same triple product regrouped (pattern B:
   // (v (.) x) . A).  Either way the intermediate - 4 GiB for CP with r = n = 1024 - never exists.  fp32 only (the
   // KR loader lives in k_mfma_f32); CTN_FUSE=0 disables, 1 fuses whenever the pattern matches (tests).
+  // By default only intermediates of at least 2^28 elements (1 GiB) are fused away: the fused GEMM runs on the
+  // register-staged kernel (a direct-to-LDS load cannot multiply), measured 13 % slower than materialising a 4 GiB
+  // product and feeding the large-tile kernel (CP, r = n = 1024: 23.4 vs 20.7 ms) - a trade of time for memory that
+  // only pays when the memory is large; at 2^31 elements it is the only way the step can run at all.
+  constexpr double kFuseMinNumel = 268435456.0;
   struct Fuse { int x = -1, y = -1, w = -1; };
   std::vector<Fuse> fuse(d.n_steps);
   std::vector<char> absorbed(d.n_steps, 0);
@@ -220,7 +225,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
           // pattern A: t1 = p (.) q element-wise, consumed by a GEMM with `other`
           bool k2 = false;
           for (int id : {t1, other}) for (int32_t l : labs[id]) if (!has(out2, l)) k2 = true;
-          const bool big = numel[t1] >= (double)(1 << 20) && numel[t1] >= 8.0 * (numel[p] + numel[q]);
+          const bool big = numel[t1] >= kFuseMinNumel && numel[t1] >= 8.0 * (numel[p] + numel[q]);
           if (k2 && gemm_ok(p, q, other, out2) && (fmode == 1 || big)) {
             // X = the factor with the larger stride pattern first is irrelevant: keep (p, q)
             fuse[s2].x = p; fuse[s2].y = q; fuse[s2].w = other; absorbed[s1] = 1;
@@ -230,7 +235,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
           bool sub = true;
           for (int32_t l : labs[other]) if (!has(t1, l)) sub = false;
           if (!sub) continue;
-          const bool big = numel[t1] >= (double)(1 << 20) && numel[t1] >= 4.0 * numel[out2] && numel[other] * 16.0 <= numel[t1];
+          const bool big = numel[t1] >= kFuseMinNumel && numel[t1] >= 4.0 * numel[out2] && numel[other] * 16.0 <= numel[t1];
           if (!(fmode == 1 || big)) continue;
           // `other` joins the side that carries more of its kept labels
           int kp = 0, kq = 0;
