@@ -229,18 +229,19 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSw
 // Same launch-size condition as split-K (the step's 128-wide tiles cannot occupy half the chip); the largest tile
 // that still gives every CU a workgroup (with one network in flight a 256 x 256 x 1024 step runs as 256 tiles of
 // 16 x 16: on 64 tiles of 32 x 32 three quarters of the matrix pipes idle and the step takes 14 us instead of ~6);
-// at most kMaxPartials tiles per replica (one abs-sum partial each), both k-offset tables in LDS.
+// at most kLatMaxTiles tiles per replica (one abs-sum partial each), both k-offset tables in LDS.
+constexpr int kLatMaxTiles = 1024;
 static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
   if (sw.lat == 0 || dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.rhs < 0 || st.modeA >= 3) return 0;
   if (st.K > kLatMaxK || st.K < 32) return 0;
   if (sw.lat != 1 && ((int64_t)st.blocks * R > n_cu / 2 || st.K < 128)) return 0;
   auto tiles = [&](int T) { return st.Bt * ((st.M + T - 1) / T) * ((st.N + T - 1) / T); };
   const int64_t t16 = tiles(16), t32 = tiles(32), t64 = tiles(64);
-  if (t64 * R >= n_cu && t64 <= kMaxPartials && st.K <= 2 * 512) return 64;
-  if (t32 * R >= n_cu && t32 <= kMaxPartials) return 32;
-  if (t16 <= kMaxPartials) return 16;
-  if (t32 <= kMaxPartials) return 32;
-  if (t64 <= kMaxPartials && st.K <= 2 * 512) return 64;
+  if (t64 * R >= n_cu && t64 <= kLatMaxTiles && st.K <= 2 * 512) return 64;
+  if (t32 * R >= n_cu && t32 <= kLatMaxTiles) return 32;
+  if (t16 <= kLatMaxTiles) return 16;
+  if (t32 <= kLatMaxTiles) return 32;
+  if (t64 <= kLatMaxTiles && st.K <= 2 * 512) return 64;
   return 0;
 }
 

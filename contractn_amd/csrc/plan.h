@@ -15,8 +15,9 @@
 
 namespace ctn {
 
-constexpr int kMaxPartials = 1024;  // abs-sum partial slots per (step, replica) at most: one wave of the consumer adds them
-                                   // (16 per lane, fixed order); a step with more workgroups goes through k_collapse
+constexpr int kMaxPartials = 4096;  // abs-sum partial slots per (step, replica) at most: one wave of the consumer adds them
+                                   // (up to 64 per lane, fixed order, loads independent); more workgroups than that
+                                   // (no kernel launches them today: the streaming grids are capped at 4096) go through k_collapse
 constexpr int kWaveOutputs = 64;   // "a handful of outputs": k_dot takes at most this many, the split-K reduce pass spreads over as many workgroups
 constexpr int kTileM = 128;        // MFMA f32 workgroup tile
 constexpr int kTileN = 128;

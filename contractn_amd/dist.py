@@ -715,8 +715,104 @@ class SlicedContraction:
         return combine_split([(t[r], logs[r]) for r in range(len(self.my_slices))])
 
     def run(self, group=None):
-        """Contract all slices of this rank, then ONE all_gather + local combine (no collective at world 1)."""
+        """Contract all slices of this rank and join the ranks' partial results.
+
+        A small result (a closed network's amplitude, a few thousand elements): ONE ``all_gather`` of the packed
+        ``(T_hat, c)`` + a local combine on the host - latency-bound, no ring.  A large open result stays on the
+        device (:meth:`run_device`): reduce-scatter + all-gather over the links, SURVEY.md 8e."""
+        if int(np.prod(self.out_shape)) >= DEVICE_JOIN_MIN_NUMEL:
+            t, c = self.run_device(group=group)
+            return t.cpu().numpy(), np.asarray(c, dtype=np.float64)
         t_loc, c_loc = self.local_result()
         if self.world == 1:
             return t_loc, c_loc
         return all_gather_combine(t_loc, c_loc, group=group, world=self.world, device=self.device)
+
+    # -- large open outputs: everything stays on the device -------------------------------------------------------
+    def local_result_device(self):
+        """This rank's slices combined ON THE DEVICE: ``(T_hat_loc [torch, out_shape], c_loc | None)``.
+
+        The slices' results ``(T_hat_s, c_s)`` sit in one device tensor ``out[s, ...]``; their split-format sum
+        ``sum_s T_hat_s e^{c_s}`` is itself a contraction - weights ``w_s = e^{c_s - c*}`` against ``out`` over the
+        slice label - so it runs on the engine like any other step and comes back stabilised.  ``None`` for the
+        scale means "this rank contributes nothing" (no slices, or all of them exact zeros)."""
+        import torch
+
+        from .einsum import contract
+
+        dev = torch.device("cuda", self.device)
+        if self.bc is None:
+            return torch.zeros(self.out_shape, device=dev, dtype=self.out_dtype_torch()), None
+        logs = np.zeros(len(self.my_slices))
+        live = np.zeros(len(self.my_slices), dtype=bool)
+        for c0, n, launch in self._chunks:
+            launch()
+            _dev_log, resc = self.bc.executor.fetch()            # waits for the group
+            from .einsum import accumulate_log_scale
+
+            for r in range(n):
+                logs[c0 + r] = accumulate_log_scale(resc[r], self.np_dtype)
+                live[c0 + r] = resc[r][-1] != 0.0                # the final tensor was rescaled: not an exact zero
+        if not live.any():
+            return torch.zeros(self.out_shape, device=dev, dtype=self.out_dtype_torch()), None
+        c_star = float(np.max(logs[live]))
+        w = np.where(live, np.exp(logs - c_star), 0.0).astype(self.np_dtype)
+        w_dev = torch.as_tensor(w, device=dev)
+        subs = "".join(chr(ord("a") + i) if i < 25 else chr(ord("A") + i - 25) for i in range(len(self.out_shape)))
+        t_loc, c_prime = contract(f"z,z{subs}->{subs}", w_dev, self.out, split_format=True)
+        return t_loc, c_star + float(c_prime)
+
+    def out_dtype_torch(self):
+        import torch
+
+        return torch.float32 if self.np_dtype == np.float32 else torch.float64
+
+    def run_device(self, group=None):
+        """Sliced contraction with a device-resident join; returns ``(T_hat [torch tensor on this rank's GPU], c)``.
+
+        Per rank: :meth:`local_result_device`.  Across ranks (large ``T_hat``): the scales cross
+        first (one 8-byte all_gather), every rank brings its tensor to the common scale ``c* = max c_g``, the sum
+        is a reduce-scatter (each rank receives and owns 1 / world of the result), the stabilising abs-sum is taken
+        on the shards (one scalar all_reduce) and the normalised shards are all-gathered: the tensor crosses the
+        links twice, in pieces that use every link, instead of world times through one rank."""
+        import torch
+        import torch.distributed as dist
+
+        t_loc, c_loc = self.local_result_device()
+        if self.world == 1:
+            return t_loc, (0.0 if c_loc is None else c_loc)
+        backend = dist.get_backend(group)
+        on_dev = backend == "nccl"
+        dev = t_loc.device
+        cs = torch.tensor([float("-inf") if c_loc is None else c_loc], dtype=torch.float64, device=dev if on_dev else "cpu")
+        all_c = [torch.empty_like(cs) for _ in range(self.world)]
+        dist.all_gather(all_c, cs, group=group)
+        c_star = max(float(x.item()) for x in all_c)
+        if c_star == float("-inf"):
+            return t_loc, 0.0                                     # every rank holds an exact zero
+        u = t_loc.reshape(-1) * (0.0 if c_loc is None else float(np.exp(c_loc - c_star)))
+        numel = u.numel()
+        if on_dev and numel % self.world == 0:
+            shard = torch.empty(numel // self.world, device=dev, dtype=u.dtype)
+            dist.reduce_scatter_tensor(shard, u, op=dist.ReduceOp.SUM, group=group)
+            norm = shard.abs().sum(dtype=torch.float64).reshape(1)
+            dist.all_reduce(norm, op=dist.ReduceOp.SUM, group=group)
+            rescale = float(norm.item()) / numel
+            if float(norm.item()) > 1e-7:
+                shard = shard / rescale
+            full = torch.empty(numel, device=dev, dtype=u.dtype)
+            dist.all_gather_into_tensor(full, shard, group=group)
+        else:   # gloo (CPU tests, one-GPU rehearsals) or a size the shards do not divide: a plain all_reduce
+            buf = u if on_dev else u.cpu()
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            full = buf.to(dev)
+            norm_v = float(full.abs().sum(dtype=torch.float64).item())
+            rescale = norm_v / numel
+            if norm_v > 1e-7:
+                full = full / rescale
+            norm = torch.tensor([norm_v])
+        c = c_star + (float(np.log(rescale)) if float(norm.item()) > 1e-7 else 0.0)
+        return full.reshape(self.out_shape), c
+
+
+DEVICE_JOIN_MIN_NUMEL = 1 << 14     # results at least this large are joined on the device (reduce-scatter + all-gather)

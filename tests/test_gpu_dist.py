@@ -155,3 +155,68 @@ def test_two_ranks_independent_subtrees_with_one_all_gather():
         assert p.exitcode == 0
     assert results[0][1:] == results[1][1:]
     assert results[0][1] == float(rt) and abs(results[0][2] - float(rc)) <= 1e-3
+
+
+def _open_network():
+    """An MPS with 7 open physical legs (4^7 = 16384 output elements) and bonds of 8."""
+    from contractn_amd import TN
+    from tests import networks as nets
+
+    return nets.mps_open(TN, (8,) * 6, (4,) * 7, dtype=np.float32, seed=12)
+
+
+def _open_rank_main(rank, world, port, label, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as tdist
+
+    from contractn_amd import dist
+
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tn = _open_network()
+        sc = dist.SlicedContraction(tn.einsum_str, list(tn.params), (label,), optimize="auto", rank=rank, world=world, device=0)
+        t, c = sc.run_device()                     # HIP engine for the slices AND for the local split-format sum
+        q.put((rank, t.cpu().numpy(), float(c)))
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_open_output_device_join_one_and_two_ranks():
+    """A LARGE open result (16384 elements) never goes through the host: per rank the slices' results are summed
+    in split format by the engine, across ranks the tensor is reduced and re-stabilised in pieces (all_reduce
+    here over gloo; reduce-scatter + all-gather over RCCL).  Equal to the unsliced contraction element by element."""
+    import torch.multiprocessing as mp
+
+    from contractn_amd import dist
+
+    tn = _open_network()
+    ops = list(tn.params)
+    lhs, out = tn.einsum_str.split("->")
+    label = next(c for c in sorted(set(lhs.replace(",", ""))) if c not in out)      # a bond: 8 slices
+    t_u, c_u = tn.contract(split_format=True)
+    ref = t_u.astype(np.float64) * np.exp(float(c_u))
+    assert ref.size == 4 ** 7 >= dist.DEVICE_JOIN_MIN_NUMEL
+    # one rank: device combine only
+    sc = dist.SlicedContraction(tn.einsum_str, ops, (label,), optimize="auto", rank=0, world=1)
+    t1, c1 = sc.run()
+    got1 = t1.astype(np.float64) * np.exp(float(c1))
+    assert np.max(np.abs(got1 - ref)) <= 1e-4 * np.max(np.abs(ref))
+    assert abs(np.mean(np.abs(t1)) - 1.0) < 1e-4
+    # two ranks
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_open_rank_main, args=(r, 2, port, label, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((r, t, c) for r, t, c in (q.get(timeout=300) for _ in procs))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for _r, t, c in results:
+        got = t.astype(np.float64) * np.exp(c)
+        assert np.max(np.abs(got - ref)) <= 1e-4 * np.max(np.abs(ref))
+        assert abs(np.mean(np.abs(t)) - 1.0) < 1e-4
+    assert np.array_equal(results[0][1], results[1][1]) and results[0][2] == results[1][2]
