@@ -250,10 +250,22 @@ static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitche
 // a batch leg, or a fused step whose output is a quarter of the GEMM it replaced - as long as the tile count still
 // fits the step's partial-sum region.  Steps the planner made eligible for the large-tile kernel keep 128-unit
 // counting (their fallback must agree with it), and so do steps that already go through the collapse pass.
-static void plain_tiles(const Step& st, int R, int n_cu, int* tm, int* tn) {
+static bool g_launch(const Step& st, int R, int n_cu, int use_g) {
+  // does a launch of this (planner-eligible) step take the large-tile LDS-DMA kernel?  At least two of the big tiles
+  // per CU and K >= 192 (below that the 128-tile kernel's 3-4 workgroups per CU hide the per-tile cost better), or a
+  // long K (>= 1024) from 3/4 of a tile per CU; CTN_MFMA_G=2: whenever eligible (tests)
+  if (!use_g || st.kernel != CTN_KERNEL_MFMA_F32 || st.tileM != 256) return false;
+  const int64_t gtiles = st.Bt * ((st.M + 255) / 256) * ((st.N + st.tileN - 1) / st.tileN) * R;
+  return use_g >= 2 || (gtiles >= 2LL * n_cu && st.K >= 192) || (st.K >= 1024 && 4 * gtiles >= 3LL * n_cu);
+}
+
+static void plain_tiles(const Step& st, int R, int n_cu, int use_g, bool is_last, int* tm, int* tn) {
   *tm = st.tileM == 64 ? 64 : kTileM;
   *tn = st.tileN;
-  if (st.kernel != CTN_KERNEL_MFMA_F32 || st.tileM == 256 || st.collapse) return;
+  if (st.kernel != CTN_KERNEL_MFMA_F32 || st.collapse) return;
+  // a step the planner made eligible for the large-tile kernel keeps 128-unit counting when that kernel will (or,
+  // for the caller's possibly unaligned final buffer, may) take it
+  if (st.tileM == 256 && (is_last || g_launch(st, R, n_cu, use_g))) return;
   auto tiles = [&](int a, int b) { return st.Bt * ((st.M + a - 1) / a) * ((st.N + b - 1) / b); };
   while (tiles(*tm, *tn) * R < 2LL * n_cu) {
     int a = *tm, b = *tn;
@@ -483,8 +495,7 @@ static int exec_launch_steps(Exec* E) {
         // better (8192 x 8192 x K: K = 64 old +7 %, 128 +2 %, 192 equal, 256 large tiles +5 %)
         // ... and long K (>= 1024) already from 3/4 of a tile per CU: the per-tile cost amortises over the k loop
         // (256 x 256 x 1024 per replica, R = 96 / 128: 86.9 / 106.2 vs 80.3 / 95.8 TFLOP/s; R = 48 / 64 lose)
-        if (use_g && st.tileM == GM && a.c_vec &&
-            (use_g >= 2 || (gtiles >= 2LL * E->n_cu && st.K >= 192) || (st.K >= 1024 && 4 * gtiles >= 3LL * E->n_cu))) {
+        if (g_launch(st, R, E->n_cu, use_g) && a.c_vec) {
           a.tiles_m = (int32_t)((st.M + GM - 1) / GM);
           // long-K steps on narrow outputs whose tiles are all full also exist as 256 x 256 tiles (8 waves, one
           // workgroup per CU): with N <= 512 each A tile is fetched half as often (256 x 256 x 1024 per replica:
@@ -522,7 +533,7 @@ static int exec_launch_steps(Exec* E) {
         }
         // register-staged tiles; halved (128 -> 64 rows / columns) while the launch is under-filled - see plain_tiles
         int tm = row_tile, tn = st.tileN;
-        plain_tiles(st, R, E->n_cu, &tm, &tn);
+        plain_tiles(st, R, E->n_cu, E->mfma_g, s + 1 == P.n_steps, &tm, &tn);
         a.tiles_m = (int32_t)((st.M + tm - 1) / tm);
         a.tiles_n = (int32_t)((st.N + tn - 1) / tn);
         a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
@@ -939,9 +950,9 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     else if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
                           rowdot_splits(st, replicas, E.n_cu)))
       E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kWaveOutputs, P.tensors[st.out].numel / 1024));
-    else if (st.kernel == CTN_KERNEL_MFMA_F32 && !st.collapse && st.tileM != 256) {
+    else if (st.kernel == CTN_KERNEL_MFMA_F32 && !st.collapse) {
       int tm, tn;
-      plain_tiles(st, replicas, E.n_cu, &tm, &tn);
+      plain_tiles(st, replicas, E.n_cu, E.mfma_g, s + 1 == P.n_steps, &tm, &tn);
       E.step_partials[s] = (int)(st.Bt * ((st.M + tm - 1) / tm) * ((st.N + tn - 1) / tn));
     }
     E.step_off[s] = E.part_slots;

@@ -70,6 +70,10 @@ def summarize(name, bc, wall, by, replicas, extra=None):
                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None}
                     for k, v in by.items()},
     }
+    tiles = {}
+    for t in bc.executor.step_tiles():
+        tiles[str(t)] = tiles.get(str(t), 0) + 1
+    line["tiles"] = tiles
     if extra:
         line.update(extra)
     print(json.dumps(line), flush=True)
