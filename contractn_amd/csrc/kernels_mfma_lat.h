@@ -31,9 +31,15 @@ constexpr int kLatMaxK = 4096;      // k-offset tables of both operands in LDS: 
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int T>
-__global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
+typedef double f64x4v __attribute__((ext_vector_type(4)));
+
+// F = float: T = 16 / 32 / 64 as above.  F = double: T = 16 only (v_mfma_f64_16x16x4_f64; the fp64 accumulator
+// keeps row (lane >> 4) + 4 * reg, not 4 * (lane >> 4) + reg like the fp32 one).
+template <int T, typename F = float>
+__global__ __launch_bounds__(512) void k_mfma_lat(StepArgs a, int kchunk) {
   static_assert(T == 16 || T == 32 || T == 64, "tile edge");
+  static_assert(std::is_same<F, float>::value || T == 16, "fp64: 16 x 16 tiles only");
+  constexpr bool F64 = std::is_same<F, double>::value;
   constexpr int MB = T == 16 ? 16 : 32;        // MFMA block edge
   constexpr int KP = T == 16 ? 4 : 2;          // k per MFMA (16x16x4 / 32x32x2)
   constexpr int NA = MB * MB / 64;             // accumulator registers per lane (4 / 16)
@@ -41,7 +47,7 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
   constexpr int KS = 8 / (Q * Q);              // K splits (waves per block)
   constexpr int EPT = (T * T + 511) / 512;     // output elements per thread (T = 16: threads 0..255 one each)
   __shared__ int s_okA[kLatMaxK], s_okB[kLatMaxK];
-  __shared__ __attribute__((aligned(16))) float s_part[8][MB * MB];   // one partial block per wave
+  __shared__ __attribute__((aligned(16))) F s_part[8][MB * MB];       // one partial block per wave
   __shared__ double red[8];
 
   const int tid = threadIdx.x;
@@ -58,9 +64,9 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
   const int qm = (q / Q) * MB, qn = (q % Q) * MB;
 
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
-  const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
-  const float* __restrict__ B = (const float*)tp[a.idB] + a.obB[b];
-  float* __restrict__ C = (float*)tp[a.idC] + a.obC[b];
+  const F* __restrict__ A = (const F*)tp[a.idA] + a.obA[b];
+  const F* __restrict__ B = (const F*)tp[a.idB] + a.obB[b];
+  F* __restrict__ C = (F*)tp[a.idC] + a.obC[b];
 
   // ONE round trip for everything that does not depend on other loads - requested back to back, first used at the
   // table copy below: the producers' abs-sum partials (reduced to the rescale factors after the loop, like
@@ -93,31 +99,32 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
   for (int i = 0; i < EPT; ++i) asm volatile("" : "+v"(offc[i]));
   __syncthreads();
 
-  typedef typename std::conditional<T == 16, f32x4v, f32x16>::type acc_t;
+  typedef typename std::conditional<F64, f64x4v, typename std::conditional<T == 16, f32x4v, f32x16>::type>::type acc_t;
   acc_t acc;
 #pragma unroll
-  for (int e = 0; e < NA; ++e) acc[e] = 0.f;
-  auto mfma = [&](float x, float y) {
-    if constexpr (T == 16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc, 0, 0, 0);
+  for (int e = 0; e < NA; ++e) acc[e] = 0;
+  auto mfma = [&](F x, F y) {
+    if constexpr (F64) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc, 0, 0, 0);
+    else if constexpr (T == 16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc, 0, 0, 0);
     else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
   };
   const int kbeg = ks * kchunk, kend = min(a.K, kbeg + kchunk);   // kchunk is a multiple of KP; a wave may own nothing
-  const float* __restrict__ pa = A + offA;
-  const float* __restrict__ pb = B + offB;
+  const F* __restrict__ pa = A + offA;
+  const F* __restrict__ pb = B + offB;
   // Rounds of U MFMA steps, software-pipelined over two register sets: the 2U gathers of round r + 1 (their table
   // look-ups are LDS reads) are all in flight while the U MFMAs of round r issue.  U = 32: a wave's share of a
   // K = 1024 step is one or two rounds, i.e. ALL its loads are requested before its first MFMA - one L2 round trip
   // per step instead of one per round.
-  constexpr int U = 32;
-  float xa0[U], xb0[U], xa1[U], xb1[U];
-  auto LOAD = [&](float (&ya)[U], float (&yb)[U], int k0) {
+  constexpr int U = F64 ? 16 : 32;     // (fp64 operands take two registers each)
+  F xa0[U], xb0[U], xa1[U], xb1[U];
+  auto LOAD = [&](F (&ya)[U], F (&yb)[U], int k0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       ya[u] = pa[s_okA[k0 + KP * u + kq]];
       yb[u] = pb[s_okB[k0 + KP * u + kq]];
     }
   };
-  auto MMA = [&](const float (&ya)[U], const float (&yb)[U]) {
+  auto MMA = [&](const F (&ya)[U], const F (&yb)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) mfma(ya[u], yb[u]);
   };
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
   int k = kbeg + KP * U * nround;
   // leftover of fewer than U steps: groups of 4 steps with their 8 gathers in flight together
   for (; k + 4 * KP <= kend; k += 4 * KP) {
-    float ya[4], yb[4];
+    F ya[4], yb[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { ya[u] = pa[s_okA[k + KP * u + kq]]; yb[u] = pb[s_okB[k + KP * u + kq]]; }
 #pragma unroll
@@ -147,8 +154,8 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
   for (; k < kend; k += KP) {                                      // tail: masked k (a zero pair adds nothing)
     const int kk = k + kq;
     const bool in = kk < kend;
-    const float xa = in ? pa[s_okA[kk]] : 0.f;
-    const float xb = in ? pb[s_okB[kk]] : 0.f;
+    const F xa = in ? pa[s_okA[kk]] : (F)0;
+    const F xb = in ? pb[s_okB[kk]] : (F)0;
     mfma(xa, xb);
   }
 
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
   // (e&3)+8(e>>2)+4h; 16 x 16: register e of lane (col, g) is row 4g+e
 #pragma unroll
   for (int e = 0; e < NA; ++e) {
-    const int row = T == 16 ? 4 * kq + e : (e & 3) + 8 * (e >> 2) + 4 * kq;
+    const int row = F64 ? kq + 4 * e : (T == 16 ? 4 * kq + e : (e & 3) + 8 * (e >> 2) + 4 * kq);
     s_part[w][row * MB + lr] = acc[e];
   }
   __syncthreads();
@@ -166,12 +173,12 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
   pvb = lane < a.PB ? pvb : 0.0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { pva += __shfl_xor(pva, o, 64); pvb += __shfl_xor(pvb, o, 64); }
-  const float nA = (float)pva, nB = (float)pvb;
-  const float scA = (a.partA && nA > (float)a.min_norm) ? nA / (float)a.numelA : 1.f;
-  const float scB = (a.partB && nB > (float)a.min_norm) ? nB / (float)a.numelB : 1.f;
+  const F nA = (F)pva, nB = (F)pvb;
+  const F scA = (a.partA && nA > (F)a.min_norm) ? nA / (F)a.numelA : (F)1;
+  const F scB = (a.partB && nB > (F)a.min_norm) ? nB / (F)a.numelB : (F)1;
   // every thread finishes up to EPT elements: the KS partials of its block in wave order, lazy rescale, store
-  const float iA = 1.0f / scA, iB = 1.0f / scB;
-  float asum = 0.f;
+  const F iA = (F)1 / scA, iB = (F)1 / scB;
+  F asum = 0;
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
     const int idx = tid + 512 * i;                 // element of the tile, column fastest
@@ -179,13 +186,13 @@ __global__ __launch_bounds__(512) void k_mfma_f32_lat(StepArgs a, int kchunk) {
       const int row = idx / T, col = idx % T;
       const int qq = (row / MB) * Q + (col / MB);
       const int off = (row % MB) * MB + (col % MB);
-      float v = s_part[qq][off];
+      F v = s_part[qq][off];
 #pragma unroll
       for (int s = 1; s < KS; ++s) v += s_part[qq + s * Q * Q][off];
       v = (v * iA) * iB;
       if (m0 + row < a.M && n0 + col < a.N) {
         C[offc[i]] = v;
-        asum += fabsf(v);
+        asum += fabs(v);
       }
     }
   }

@@ -427,6 +427,29 @@ def test_latency_mode_one_launch(einstr, shapes, replicas, tile):
     np.testing.assert_allclose(ti.astype(np.float64) * np.exp(float(ci)), refi, rtol=1e-6, atol=1e-6 * np.max(np.abs(refi)))
 
 
+@pytest.mark.parametrize("einstr,shapes,replicas", [
+    ("mk,kn->mn", [(256, 1024), (1024, 256)], 1),      # the MPS environment step in double precision
+    ("km,kn->mn", [(300, 70), (300, 100)], 1),         # ragged everything
+    ("xkm,xkn->xmn", [(2, 160, 64), (2, 160, 96)], 2),  # batch label, two networks in flight
+    ("mk,nk->mn", [(130, 200), (90, 200)], 1),         # both k-contiguous
+])
+def test_latency_mode_one_launch_fp64(einstr, shapes, replicas):
+    """The same one-launch form in double precision: 16 x 16 tiles on v_mfma_f64_16x16x4_f64 (its accumulator rows
+    are laid out differently from the fp32 one: a transposed store would pass no test with a symmetric product)."""
+    rng = np.random.default_rng(8)
+    sets = [[rng.standard_normal(s) for s in shapes] for _ in range(replicas)]
+    bc = E.BatchedContraction(einstr, shapes, np.float64, optimize=((0, 1),), replicas=replicas)
+    t, c = bc.run_host(sets)
+    assert bc.executor.step_tiles() == [(16, 16)]
+    for r in range(replicas):
+        ref = np.einsum(einstr, *sets[r])
+        got = t[r] * np.exp(float(c[r]))
+        assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+    t2, c2 = bc.run_host(sets)
+    assert np.array_equal(t2, t) and np.array_equal(c2, c)
+    bc.executor.close()
+
+
 def test_latency_mode_feeds_rescaled_intermediates(monkeypatch):
     """A chain of latency-form steps (forced also for its short-K steps): every step consumes its predecessor's
     un-normalised output and abs-sum partials (one per tile) exactly like the throughput kernels' outputs."""
