@@ -230,7 +230,7 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSw
 // that still gives every CU a workgroup (with one network in flight a 256 x 256 x 1024 step runs as 256 tiles of
 // 16 x 16: on 64 tiles of 32 x 32 three quarters of the matrix pipes idle and the step takes 14 us instead of ~6);
 // at most kLatMaxTiles tiles per replica (one abs-sum partial each), both k-offset tables in LDS.
-constexpr int kLatMaxTiles = 1024;
+constexpr int kLatMaxTiles = kMaxPartials;
 static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
   const bool f64 = dtype == CTN_F64 && st.kernel == CTN_KERNEL_MFMA_F64;
   if (sw.lat == 0 || !(f64 || (dtype == CTN_F32 && st.kernel == CTN_KERNEL_MFMA_F32)) || st.rhs < 0 || st.modeA >= 3) return 0;
@@ -239,12 +239,14 @@ static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitche
   if (sw.lat != 1 && ((int64_t)st.blocks * R > n_cu / 2 || st.K < 128)) return 0;
   auto tiles = [&](int T) { return st.Bt * ((st.M + T - 1) / T) * ((st.N + T - 1) / T); };
   const int64_t t16 = tiles(16), t32 = tiles(32), t64 = tiles(64);
-  if (f64) return t16 <= kLatMaxTiles ? 16 : 0;     // fp64: 16 x 16 tiles (v_mfma_f64_16x16x4_f64) only
-  if (t64 * R >= n_cu && t64 <= kLatMaxTiles && st.K <= 2 * 512) return 64;
-  if (t32 * R >= n_cu && t32 <= kLatMaxTiles) return 32;
-  if (t16 <= kLatMaxTiles) return 16;
-  if (t32 <= kLatMaxTiles) return 32;
-  if (t64 <= kLatMaxTiles && st.K <= 2 * 512) return 64;
+  // ... and not more than ~1.5 workgroups per CU: beyond that split-K with its LDS-staged 64 x 64 tiles wins
+  // (100-site D = 256 network: R = 4 3.49 vs 4.21 ms for split-K, R = 8 5.83 vs 5.05 ms)
+  auto fits = [&](int64_t t) { return t <= kLatMaxTiles && (sw.lat == 1 || 2 * t * R <= 3LL * n_cu); };
+  if (f64) return fits(t16) ? 16 : 0;     // fp64: 16 x 16 tiles (v_mfma_f64_16x16x4_f64) only
+  if (t64 * R >= n_cu && fits(t64) && st.K <= 2 * 512) return 64;
+  if (t32 * R >= n_cu && fits(t32)) return 32;
+  if (fits(t16)) return 16;
+  if (fits(t32)) return 32;
   return 0;
 }
 
