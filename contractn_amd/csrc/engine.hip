@@ -278,7 +278,7 @@ static void plain_tiles(const Step& st, int R, int n_cu, int use_g, bool is_last
     if (b == 128 && st.N > 64) b = 64;
     else if (a == 128 && st.M > 64) a = 64;
     else break;
-    if (tiles(a, b) > kMaxPartials) break;
+    if (tiles(a, b) > 4096) break;
     *tm = a; *tn = b;
   }
 }
@@ -418,6 +418,7 @@ static int exec_launch_steps(Exec* E) {
     a.partC_stride = st.collapse ? st.blocks : part_stride;
     int collapse_blocks = st.blocks;   // partials written per replica when the step collapses (a launcher may retile)
     bool reduced = false;              // a K-split streaming / row-dot step: its reduce pass wrote the partials itself
+    bool do_collapse = st.collapse;    // more workgroup partials than slots: through the scratch buffer and k_collapse
     a.min_norm = P.min_norm;
     a.Bt = (int32_t)st.Bt; a.M = (int32_t)st.M; a.N = (int32_t)st.N; a.K = (int32_t)st.K;
     a.idA = st.lhs; a.idB = st.rhs >= 0 ? st.rhs : E->n_tensors - 1; a.idC = st.out;
@@ -542,7 +543,14 @@ static int exec_launch_steps(Exec* E) {
         a.tiles_m = (int32_t)((st.M + tm - 1) / tm);
         a.tiles_n = (int32_t)((st.N + tn - 1) / tn);
         a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
-        if (!st.collapse) a.partC_stride = part_stride;       // == blocks_per_replica (ctn_exec_create used the same rule)
+        if (a.blocks_per_replica > kMaxPartials) {             // (halved tiles may exceed the slots: collapse them)
+          do_collapse = true;
+          collapse_blocks = a.blocks_per_replica;
+          a.partC = E->d_scratch;
+          a.partC_stride = collapse_blocks;
+        } else {
+          a.partC_stride = part_stride;                        // == blocks_per_replica (ctn_exec_create used the same rule)
+        }
         used_tile(tm, tn);
         launch_mfma(st.modeA, st.modeB, tm, tn, dim3((unsigned)((int64_t)a.blocks_per_replica * R)), E->stream, a, E->sw);
         break;
@@ -684,7 +692,7 @@ static int exec_launch_steps(Exec* E) {
         break;
       }
     }
-    if (st.collapse && !reduced)
+    if (do_collapse && !reduced)
       hipLaunchKernelGGL(k_collapse, dim3(R), dim3(256), 0, E->stream, (const double*)E->d_scratch, collapse_blocks, part_dst);
     if (E->eager_rescale && P.stabilize && s + 1 < P.n_steps) {   // the final tensor is normalised by k_finalize
       const int64_t numel = P.tensors[st.out].numel;
@@ -932,7 +940,6 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   HIPCHECK_X(hipMalloc((void**)&E.d_tables, std::max<size_t>(P.tables.size(), 4) * 4));
   HIPCHECK_X(hipMemcpy(E.d_tables, P.tables.data(), P.tables.size() * 4, hipMemcpyHostToDevice));
   HIPCHECK_X(hipMalloc((void**)&E.d_ptrs, (size_t)replicas * E.n_tensors * sizeof(void*)));
-  HIPCHECK_X(hipMalloc((void**)&E.d_scratch, (size_t)replicas * std::max<int64_t>(P.max_collapse_blocks, 1) * 8));
   {
     size_t slab_elems = 0;   // split-K scratch: S slabs shaped like the step's output, per replica
     auto splits_of = [&](const Step& st) {
@@ -957,6 +964,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   // 64 workgroups per replica; every step gets a region of exactly that many slots per replica
   E.step_partials.resize(P.n_steps);
   E.step_off.resize(P.n_steps);
+  int64_t scratch_need = std::max<int64_t>(P.max_collapse_blocks, 1);
   for (int s = 0; s < P.n_steps; ++s) {
     const Step& st = P.steps[s];
     E.step_partials[s] = std::max(st.partials, 1);
@@ -969,11 +977,14 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     else if (st.kernel == CTN_KERNEL_MFMA_F32 && !st.collapse) {
       int tm, tn;
       plain_tiles(st, replicas, E.n_cu, E.mfma_g, s + 1 == P.n_steps, &tm, &tn);
-      E.step_partials[s] = (int)(st.Bt * ((st.M + tm - 1) / tm) * ((st.N + tn - 1) / tn));
+      const int64_t tiles = st.Bt * ((st.M + tm - 1) / tm) * ((st.N + tn - 1) / tn);
+      E.step_partials[s] = tiles > kMaxPartials ? 1 : (int)tiles;     // halved tiles beyond the slots: collapsed at launch
+      scratch_need = std::max<int64_t>(scratch_need, tiles);
     }
     E.step_off[s] = E.part_slots;
     E.part_slots += E.step_partials[s];
   }
+  HIPCHECK_X(hipMalloc((void**)&E.d_scratch, (size_t)replicas * scratch_need * 8));
   HIPCHECK_X(hipMalloc((void**)&E.d_partials, (size_t)E.part_slots * replicas * 8));
   HIPCHECK_X(hipMemset(E.d_partials, 0, (size_t)E.part_slots * replicas * 8));
   {
