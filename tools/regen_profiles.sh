@@ -1,16 +1,21 @@
 #!/bin/bash
 # Regenerate the evidence under profiles/ on a GPU box (run from the repo root):
-#   gpurun --timeout 1200 -- 'bash tools/regen_profiles.sh'      then, back in the container,
-#   python profiles/make_summary.py r01 gpurun_out/prof_r01 gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq
-#   cp gpurun_out/bench_default.json profiles/r01_bench.json; cp gpurun_out/bench_f64.json profiles/r01_bench_f64.json
-# Counters are collected in their own passes (no trace domains next to --pmc).
-set -e -o pipefail
+#   gpurun --timeout 1200 -- 'bash tools/regen_profiles.sh r02'      then, back in the container,
+#   python profiles/make_summary.py r02 gpurun_out/prof_r02 gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq gpurun_out/bench_default.json
+#   cp gpurun_out/bench_default.json profiles/r02_bench.json; cp gpurun_out/bench_f64.json profiles/r02_bench_f64.json
+# Counters are collected in their own passes (no trace domains next to --pmc); the program itself follows `--`.
+set -o pipefail
+tag=${1:-r02}
 mkdir -p gpurun_out
-B="--no-cpu-baseline"
-timeout -k 10 400 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-timeout -k 10 300 python bench.py --dtype f64 --replicas 256 --cpu-seconds 5 > gpurun_out/bench_f64.json 2> gpurun_out/bench_f64.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01 -- python3 bench.py $B > gpurun_out/prof_r01.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 $B > gpurun_out/pmc_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 $B > gpurun_out/pmc_write.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_sq -- python3 bench.py --steps 2 --warmup 1 $B > gpurun_out/pmc_sq.log 2>&1
-tail -1 gpurun_out/bench_default.json | cut -c1-400
+B="--no-cpu-baseline --no-peps"
+R=$GRAFT_REPO_ROOT
+run() { name=$1; secs=$2; shift 2; echo "== $name"; timeout -k 10 $secs "$@" > $R/gpurun_out/$name.log 2>&1; rc=$?; echo "== $name rc=$rc"; [ $rc -ge 124 ] && exit $rc; return 0; }
+timeout -k 10 500 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench_default rc=$?"
+timeout -k 10 300 python bench.py --dtype f64 --replicas 256 --cpu-seconds 5 --no-peps > gpurun_out/bench_f64.json 2> gpurun_out/bench_f64.err; echo "bench_f64 rc=$?"
+cd /tmp && export TMPDIR=/tmp
+run prof_$tag 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py $B
+run pmc_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 $B
+run pmc_write 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 $B
+run pmc_sq 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_sq -- python3 $R/bench.py --steps 2 --warmup 1 $B
+cd $R
+tail -1 gpurun_out/bench_default.json | cut -c1-300
