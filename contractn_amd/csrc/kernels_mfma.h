@@ -308,94 +308,6 @@ struct LoaderOf<4, BK, ROWS> { typedef TileLoaderKRV<1, BK, ROWS> type; };
 template <int BK, int ROWS>
 struct LoaderOf<5, BK, ROWS> { typedef TileLoaderKRV<2, BK, ROWS> type; };
 
-// the MFMA phase of one k-tile: fragments from the LDS images cA / cB, reads one k-step ahead of the MFMAs
-template <int BK, int NI, int NJ, int stepA, int stepB>
-__device__ __forceinline__ void mfma_tile(const float* __restrict__ cA, const float* __restrict__ cB, const int (&fax)[NI],
-                                          const int (&fbx)[NJ], f32x16 (&acc)[NI][NJ]) {
-  float fa[2][NI], fb[2][NJ];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) fa[0][i] = cA[fax[i]];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) fb[0][j] = cB[fbx[j]];
-#pragma unroll
-  for (int kk = 0; kk < BK / 2; ++kk) {
-    const int c = kk & 1, nx = c ^ 1;
-    if (kk + 1 < BK / 2) {
-#pragma unroll
-      for (int i = 0; i < NI; ++i) fa[nx][i] = cA[fax[i] + (kk + 1) * stepA];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[nx][j] = cB[fbx[j] + (kk + 1) * stepB];
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
-    // pin the interleave: the LDS reads of step kk+1 issue ahead of the MFMAs of step kk
-    __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
-  }
-}
-
-// Skinny tiles (64 rows or 64 columns: PEPS boundary absorptions, 16 flop/B) sit at the HBM ridge, and their
-// MFMA phase per 16-deep k-tile (~0.45 us) is far shorter than a trip to HBM (~2 us): with ONE k-tile of loads in
-// flight per workgroup the loop waits on memory every iteration.  This form keeps TWO in flight - two register
-// sets, tile t + 2 requested while tile t is multiplied and tile t + 1 is still on its way - at the price of a
-// dozen registers (these tiles stage 4 + 8 floats per thread and k-tile).
-template <int MA, int MB, int BK, int TN, bool FULL, int BM>
-__device__ __forceinline__ void mfma_mainloop_pf2(const int32_t* __restrict__ omA, const int32_t* __restrict__ onB, int m0, int n0,
-                                                  int M, int N, const float* __restrict__ A, const float* __restrict__ B,
-                                                  const int32_t* __restrict__ okA, const int32_t* __restrict__ okB,
-                                                  int K, float* sA, float* sB, f32x16 (&acc)[BM / 64][TN / 64], int tid) {
-  using LA = TileLoader<MA, BK, BM>;
-  using LB = TileLoader<MB, BK, TN>;
-  constexpr int SZA = LA::kSize, SZB = LB::kSize;
-  constexpr int NJ = TN / 64, NI = BM / 64;
-  const int lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * (BM / 2), wn = (w & 1) * (TN / 2);
-  const int l31 = lane & 31, h = lane >> 5;
-  LA la0, la1;
-  LB lb0, lb1;
-  la0.init(omA, m0, M, tid); la1.init(omA, m0, M, tid);
-  lb0.init(onB, n0, N, tid); lb1.init(onB, n0, N, tid);
-  const int nkt = (K + BK - 1) / BK;
-  la0.tab(okA, 0, tid); lb0.tab(okB, 0, tid);
-  la0.load(A); lb0.load(B);                                   // tile 0 -> set 0
-  la1.tab(okA, BK, tid); lb1.tab(okB, BK, tid);
-  if (nkt > 1) { la1.load(A); lb1.load(B); }                  // tile 1 -> set 1
-  la0.tab(okA, 2 * BK, tid); lb0.tab(okB, 2 * BK, tid);       // table entries of the tiles each set takes next
-  la1.tab(okA, 3 * BK, tid); lb1.tab(okB, 3 * BK, tid);
-  la0.template store<FULL>(sA, 0, K, tid);
-  lb0.template store<FULL>(sB, 0, K, tid);
-  __syncthreads();
-  int fax[NI], fbx[NJ];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) fax[i] = LA::idx(wm + i * 32 + l31, h);
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) fbx[j] = LB::idx(wn + j * 32 + l31, h);
-  constexpr int stepA = MA == 2 ? 2 : 2 * BM, stepB = MB == 2 ? 2 : 2 * TN;
-  // Y: the set whose tile (kt) is already in LDS - it takes tile kt + 2; X: the set holding tile kt + 1, in flight
-  auto iter = [&](LA& laY, LB& lbY, LA& laX, LB& lbX, int kt) {
-    const int cur = kt & 1;
-    if (kt + 2 < nkt) {
-      laY.load(A); lbY.load(B);
-      laY.tab(okA, (kt + 4) * BK, tid); lbY.tab(okB, (kt + 4) * BK, tid);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_tile<BK, NI, NJ, stepA, stepB>(sA + cur * SZA, sB + cur * SZB, fax, fbx, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nkt) {
-      laX.template store<FULL>(sA + (cur ^ 1) * SZA, (kt + 1) * BK, K, tid);
-      lbX.template store<FULL>(sB + (cur ^ 1) * SZB, (kt + 1) * BK, K, tid);
-    }
-    __syncthreads();
-  };
-  for (int kt = 0; kt < nkt; kt += 2) {
-    iter(la0, lb0, la1, lb1, kt);
-    if (kt + 1 < nkt) iter(la1, lb1, la0, lb0, kt + 1);
-  }
-}
-
 template <int MA, int MB, int BK, int TN, bool FULL, int BM>
 __device__ __forceinline__ void mfma_mainloop(typename LoaderOf<MA, BK, BM>::type& la, TileLoader<MB, BK, TN>& lb,
                                               const float* __restrict__ A, const float* __restrict__ B,
@@ -445,7 +357,31 @@ __device__ __forceinline__ void mfma_mainloop(typename LoaderOf<MA, BK, BM>::typ
       lb.tab(okB, (kt + 2) * BK, tid);
     }
     __builtin_amdgcn_sched_barrier(0);  // global loads stay in front of the MFMA phase
-    mfma_tile<BK, NI, NJ, stepA, stepB>(sA + cur * SZA, sB + cur * SZB, fax, fbx, acc);
+    const float* cA = sA + cur * SZA;
+    const float* cB = sB + cur * SZB;
+    float fa[2][NI], fb[2][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) fa[0][i] = cA[fax[i]];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) fb[0][j] = cB[fbx[j]];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int c = kk & 1, nx = c ^ 1;
+      if (kk + 1 < BK / 2) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fa[nx][i] = cA[fax[i] + (kk + 1) * stepA];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[nx][j] = cB[fbx[j] + (kk + 1) * stepB];
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c][j], acc[i][j], 0, 0, 0);
+      // pin the interleave: the LDS reads of step kk+1 issue ahead of the MFMAs of step kk
+      __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);  // the staged tile is consumed only after the MFMA phase
     if (more) {
       la.template store<FULL>(sA + (cur ^ 1) * SZA, (kt + 1) * BK, K, tid);
@@ -531,14 +467,8 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
 #endif
   // FULL: the tile lies completely inside M x N and K is a multiple of BK -> no masking
   const bool full = (m0 + BM <= a.M) && (n0 + TN <= a.N) && (a.K % BK == 0);
-  constexpr bool PF2 = (BM == 64 || TN == 64) && BK == 16 && MA < 3;   // skinny tiles: two k-tiles of loads in flight
-  if constexpr (PF2) {
-    if (full) mfma_mainloop_pf2<MA, MB, BK, TN, true, BM>(a.omA, a.onB, m0, n0, a.M, a.N, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid);
-    else mfma_mainloop_pf2<MA, MB, BK, TN, false, BM>(a.omA, a.onB, m0, n0, a.M, a.N, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid);
-  } else {
-    if (full) mfma_mainloop<MA, MB, BK, TN, true, BM>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
-    else mfma_mainloop<MA, MB, BK, TN, false, BM>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
-  }
+  if (full) mfma_mainloop<MA, MB, BK, TN, true, BM>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
+  else mfma_mainloop<MA, MB, BK, TN, false, BM>(la, lb, A, B, a.okA, a.okB, a.K, sA, sB, acc, tid, stamp1);
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 2] = __builtin_amdgcn_s_memtime();
 #endif
