@@ -363,6 +363,11 @@ def run_mps(args, world, rank, local_rank, backend, dev):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(einstr, shapes, path, flat[0], offs, numels, args.cpu_seconds,
                                               float(t_hat[0]), float(logs[0]), f64)
+        if R > 1:   # ... and the LAST replica of the launch against the oracle as well (one more CPU contraction)
+            extra = cpu_baseline(einstr, shapes, path, flat[R - 1], offs, numels, 0.0, float(t_hat[R - 1]), float(logs[R - 1]), f64)
+            pv = result["cpu_baseline"]["parity_vs_gpu"]
+            pv["last_replica"] = extra["parity_vs_gpu"]
+            pv["ok"] = bool(pv["ok"] and extra["parity_vs_gpu"]["ok"])
     return result if rank == 0 else None
 
 
