@@ -46,6 +46,7 @@ struct DevSwitches {
   int mfma_g = 1;        // CTN_MFMA_G: 0 never use the large-tile LDS-DMA kernels, 1 when a launch fills the chip, 2 whenever eligible (tests)
   int graph = 1;         // CTN_GRAPH=0: every enqueue issues its launches one by one
   int mfma_bk = 0;       // CTN_MFMA_BK=16|32: force the k-tile depth of k_mfma_f32
+  int lat64_min_k = 512; // CTN_LAT64_MIN_K: least K for the 64 x 64 one-launch latency form when an operand is k-contiguous
   int splitk = -1;       // CTN_SPLITK: 0 disables the latency mode, 1 forces it for every eligible step (tests)
   int splitk_max = 0;    // CTN_SPLITK_MAX: tile-count threshold of the latency mode
   int lat = -1;          // CTN_LAT: 0 never use the one-launch latency form (k_mfma_f32_lat), 1 whenever the shape allows (tests)
@@ -63,6 +64,7 @@ static DevSwitches read_dev_switches() {
   d.splitk = num("CTN_SPLITK", -1);
   d.splitk_max = num("CTN_SPLITK_MAX", 0);
   d.lat = num("CTN_LAT", -1);
+  d.lat64_min_k = num("CTN_LAT64_MIN_K", 512);
   d.g_no_asm = getenv("CTN_G_NO_ASM") != nullptr;
   d.stamps = getenv("CTN_DEBUG_STAMPS");
   d.stamp_step = num("CTN_DEBUG_STAMP_STEP", -1);
@@ -243,7 +245,12 @@ static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitche
   // (100-site D = 256 network: R = 4 3.49 vs 4.21 ms for split-K, R = 8 5.83 vs 5.05 ms)
   auto fits = [&](int64_t t) { return t <= kLatMaxTiles && (sw.lat == 1 || 2 * t * R <= 3LL * n_cu); };
   if (f64) return fits(t16) ? 16 : 0;     // fp64: 16 x 16 tiles (v_mfma_f64_16x16x4_f64) only
-  if (t64 * R >= n_cu && fits(t64) && st.K <= 2 * 512) return 64;
+  // (a k-contiguous operand reaches the fragment registers as 4-byte loads a row stride apart; with a short K split
+  // eight ways there is nothing to pipeline them behind: 1024 x 1024 x 256, A k-contiguous, took 27.8 us on 256 tiles
+  // of 64 x 64 against 23.7 us for the LDS-staged tiles with two K slabs - while the same tile count with both
+  // operands row-contiguous, 4 x (256 x 1024 x 256), is 6 % faster here than there)
+  const bool kcontig = st.modeA == 2 || st.modeB == 2;
+  if (t64 * R >= n_cu && fits(t64) && st.K <= 2 * 512 && (!kcontig || st.K >= sw.lat64_min_k)) return 64;
   if (t32 * R >= n_cu && fits(t32)) return 32;
   if (fits(t16)) return 16;
   if (fits(t32)) return 32;

@@ -97,10 +97,15 @@ __device__ __forceinline__ T producer_scale(const double* part, int P, int strid
     return (T)1;
   }
   const int lane = threadIdx.x & 63;
-  // lane l adds partials l, l + 64, ... (P <= 1024: at most 16 independent loads), then the xor butterfly: a fixed order
+  // lane l adds partials l, l + 64, ... (P <= kMaxPartials: at most 8 loads), then the xor butterfly: a fixed order
   const double* __restrict__ pr = part + (size_t)r * stride;
   double v = 0.0;
-  for (int i = lane; i < P; i += 64) v += pr[i];
+  int i = lane;
+  for (; i + 192 < P; i += 256) {   // four independent loads in flight; added in index order as the plain loop does
+    const double d0 = pr[i], d1 = pr[i + 64], d2 = pr[i + 128], d3 = pr[i + 192];
+    v += d0; v += d1; v += d2; v += d3;
+  }
+  for (; i < P; i += 64) v += pr[i];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   const T norm = (T)v;

@@ -161,7 +161,51 @@ __global__ __launch_bounds__(256) void k_stream_kvec(StepArgs a) {
   T* __restrict__ C = (T*)tp[a.idC];
   const uint32_t outs = (uint32_t)a.H * (uint32_t)a.L * (uint32_t)a.Nv;
   double absv = 0;
-  for (uint32_t o = blockIdx.x * 256u + threadIdx.x; o < outs; o += gridDim.x * 256u) {
+  const uint32_t stride = gridDim.x * 256u;          // <= 2^20, outs < 2^31: o + 3 * stride cannot wrap
+  uint32_t o = blockIdx.x * 256u + threadIdx.x;
+  // four outputs of a thread at a time (its rounds o, o + stride, ...): their operand vectors are requested
+  // together - with one output per round a thread has a single 16-byte load in flight (20 MB step: 1.7 TB/s)
+  constexpr int U = 4;
+  for (; o + (U - 1) * stride < outs; o += U * stride) {
+    const T* pa[U];
+    const T* pb[U];
+    size_t co[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t ou = o + u * stride;
+      const uint32_t row = a.dNv.div(ou);
+      const int n = (int)(ou - row * (uint32_t)a.Nv);
+      const int h = (int)a.dL.div(row);
+      const int l = (int)(row - (uint32_t)h * (uint32_t)a.L);
+      pa[u] = A + a.ohA[h] + a.olA[l] + (int64_t)n * a.sAn;
+      pb[u] = B + a.ohB[h] + a.olB[l] + (int64_t)n * a.sBn;
+      co[u] = (size_t)row * a.Nv + n;
+    }
+    T acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0;
+    for (int k = 0; k < a.K; k += V) {
+      VT xv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const VT*>(pa[u] + k);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int kb = a.okB[k + v];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const T x = reinterpret_cast<const T*>(&xv[u])[v];
+          const T y = pb[u][kb];
+          acc[u] = fma(da ? x / sA : x, db ? y / sB : y, acc[u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      C[co[u]] = acc[u];
+      absv += (double)fabs(acc[u]);
+    }
+  }
+  for (; o < outs; o += stride) {
     const uint32_t row = a.dNv.div(o);
     const int n = (int)(o - row * (uint32_t)a.Nv);
     const int h = (int)a.dL.div(row);

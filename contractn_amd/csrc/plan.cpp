@@ -32,6 +32,15 @@ std::string fmt(const char* f, long long a = 0, long long b = 0, long long c = 0
 int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // Row-major enumeration of a label group: table[i] = sum_j idx_j * stride_j
+// Grid of a streaming (grid-stride) step that wants `want` workgroups of 256 threads: all of them while each can keep
+// its own abs-sum partial; a step of moderate size (at most 8 rounds per thread) runs on kMaxPartials workgroups
+// rather than pay the collapse launch (5 us next to a 10 us step of a batched-MPS site); beyond that the full grid,
+// collapsed.
+int stream_grid(int64_t want) {
+  if (want <= kMaxPartials) return (int)std::max<int64_t>(want, 1);
+  return want <= kStreamMaxBlocks ? kMaxPartials : kStreamMaxBlocks;
+}
+
 void build_table(const std::vector<const LabelInfo*>& group, int which /*0 A,1 B,2 C*/,
                  int64_t padded, std::vector<int32_t>& out) {
   int64_t n = 1;
@@ -547,7 +556,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
         st.kernel = CTN_KERNEL_ELEMENT;
         st.kvec = 1;
         st.vecw = 1;
-        st.blocks = (int)std::min<int64_t>((st.H * st.L * st.Nv + 255) / 256, kStreamMaxBlocks);
+        st.blocks = stream_grid((st.H * st.L * st.Nv + 255) / 256);
       } else if (st.K >= 256 && kUnit) {
         st.kernel = CTN_KERNEL_ROWDOT;
         // persistent-style grid: at most 16 workgroups per CU, waves stride over the outputs
@@ -555,7 +564,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       } else {
         st.kernel = CTN_KERNEL_ELEMENT;
         const int64_t items = st.H * st.L * ((st.Nv + st.vecw - 1) / st.vecw);
-        st.blocks = (int)std::min<int64_t>((items + 255) / 256, kStreamMaxBlocks);
+        st.blocks = stream_grid((items + 255) / 256);
       }
     }
     st.chain_ok = outs <= kChainMaxOut && outs * st.K <= kChainMaxWork;

@@ -15,8 +15,8 @@
 
 namespace ctn {
 
-constexpr int kMaxPartials = 256;   // abs-sum partial slots per (step, replica) at most: EVERY workgroup of the consumer adds
-                                   // them (4 per lane, fixed order), so their number is paid workgroups x slots times -
+constexpr int kMaxPartials = 512;   // abs-sum partial slots per (step, replica) at most: EVERY workgroup of the consumer adds
+                                   // them (8 per lane, fixed order), so their number is paid workgroups x slots times -
                                    // 4096 slots cost a 512-workgroup GEMM 12 us; a step with more workgroups than this
                                    // goes through k_collapse (one 5 us launch, one slot)
 constexpr int kWaveOutputs = 64;   // "a handful of outputs": k_dot takes at most this many, the split-K reduce pass spreads over as many workgroups

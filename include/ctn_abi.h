@@ -104,7 +104,7 @@ typedef struct {
                           3 / 4 / 5 element-wise product of two tensors formed while the tile is staged (fused
                           step): scalar gathers / 16-byte accesses along the rows / along k */
   int32_t mode_b;
-  int32_t partials;    /* abs-sum partials per replica written by the step (<= 256; more workgroups are collapsed to 1) */
+  int32_t partials;    /* abs-sum partials per replica written by the step (<= 512; more workgroups are collapsed to 1) */
   int32_t blocks;      /* workgroups per replica */
   double flops;        /* 2*|B||M||N||K| (|B||M||N| when K is empty) + 3*numel(out) */
   int64_t out_numel;
