@@ -186,6 +186,24 @@ static void launch_mfma_a(int ma, int mb, dim3 grid, hipStream_t st, const StepA
   }
 }
 
+// epilogue-summed steps (planner pattern C): 128-row tiles, BK = 16, a plain A operand
+template <int MA, int TN>
+static void launch_mfma_epw_b(int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
+  switch (mb) {
+    case 1: hipLaunchKernelGGL((k_mfma_f32<MA, 1, 16, TN, 128, true>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_mfma_f32<MA, 2, 16, TN, 128, true>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_mfma_f32<MA, 0, 16, TN, 128, true>), grid, dim3(256), 0, st, a); break;
+  }
+}
+template <int TN>
+static void launch_mfma_epw(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
+  switch (ma) {
+    case 1: launch_mfma_epw_b<1, TN>(mb, grid, st, a); break;
+    case 2: launch_mfma_epw_b<2, TN>(mb, grid, st, a); break;
+    default: launch_mfma_epw_b<0, TN>(mb, grid, st, a); break;
+  }
+}
+
 // k-tile depth.  BK = 16: 32 KiB of LDS + 167 registers => 3 workgroups (12 waves) per CU, which
 // hides the per-tile prologue/epilogue best when K is short (MPS shapes: 108-118 TFLOP/s vs
 // 103-117 with BK = 32); BK = 32 halves the barriers per flop and wins on long-K GEMMs
@@ -197,6 +215,11 @@ static int mfma_bk(int K, const DevSwitches& sw) {
 
 // tile_m = 64: skinny rows (M <= 64 against a huge N) - always BK = 16 (these steps have a short K)
 static void launch_mfma(int ma, int mb, int tile_m, int tile_n, dim3 grid, hipStream_t st, const StepArgs& a, const DevSwitches& sw) {
+  if (a.epw) {
+    if (tile_n == 64) launch_mfma_epw<64>(ma, mb, grid, st, a);
+    else launch_mfma_epw<128>(ma, mb, grid, st, a);
+    return;
+  }
   const bool bk16 = mfma_bk(a.K, sw) == 16;
   if (tile_m == 64) {
     if (tile_n == 64) launch_mfma_a<16, 64, 64>(ma, mb, grid, st, a);
@@ -216,7 +239,7 @@ static void launch_mfma(int ma, int mb, int tile_m, int tile_n, dim3 grid, hipSt
 static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
   const int mode = sw.splitk;
   const bool mfma = (dtype == CTN_F32 && st.kernel == CTN_KERNEL_MFMA_F32) || (dtype == CTN_F64 && st.kernel == CTN_KERNEL_MFMA_F64);
-  if (mode == 0 || !mfma || st.collapse || st.K < 128 || st.modeA >= 3) return 0;
+  if (mode == 0 || !mfma || st.collapse || st.K < 128 || st.modeA >= 3 || st.epw) return 0;
   const int max_tiles = sw.splitk_max;
   const int64_t limit = max_tiles > 0 ? max_tiles : n_cu / 2;
   if (mode != 1 && (int64_t)st.blocks * R > limit) return 0;
@@ -235,7 +258,7 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSw
 constexpr int kLatMaxTiles = kMaxPartials;
 static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
   const bool f64 = dtype == CTN_F64 && st.kernel == CTN_KERNEL_MFMA_F64;
-  if (sw.lat == 0 || !(f64 || (dtype == CTN_F32 && st.kernel == CTN_KERNEL_MFMA_F32)) || st.rhs < 0 || st.modeA >= 3) return 0;
+  if (sw.lat == 0 || !(f64 || (dtype == CTN_F32 && st.kernel == CTN_KERNEL_MFMA_F32)) || st.rhs < 0 || st.modeA >= 3 || st.epw) return 0;
   if (st.K > kLatMaxK || st.K < 32) return 0;
   if (sw.mfma_g >= 2 && (f64 ? st.tileN == 128 : st.tileM == 256)) return 0;   // tests that force the large-tile kernels
   if (sw.lat != 1 && ((int64_t)st.blocks * R > n_cu / 2 || st.K < 128)) return 0;
@@ -283,7 +306,7 @@ static void plain_tiles(const Step& st, int R, int n_cu, int use_g, bool is_last
     int a = *tm, b = *tn;
     // columns first: 128 x 64 tiles measured 62 vs 45 TFLOP/s for 64 x 128 on 4096 x 1024 x 256 (one batched-MPS site)
     if (b == 128 && st.N > 64) b = 64;
-    else if (a == 128 && st.M > 64) a = 64;
+    else if (a == 128 && st.M > 64 && !st.epw) a = 64;   // (epilogue-summed steps exist for 128-row tiles only)
     else break;
     if (tiles(a, b) > 4096) break;
     *tm = a; *tn = b;
@@ -419,6 +442,7 @@ static int exec_launch_steps(Exec* E) {
     a.obA2 = T + st.t.obA2; a.omA2 = T + st.t.omA2; a.okA2 = T + st.t.okA2;
     a.idA2 = st.lhs2 >= 0 ? st.lhs2 : E->n_tensors - 1;
     a.krX = st.krX; a.krY = st.krY;
+    a.epw = st.epw;
     double* part_dst = E->d_partials + (size_t)E->step_off[s] * R;
     const int part_stride = E->step_partials[s];    // slots per replica of this step's region
     a.partC = st.collapse ? E->d_scratch : part_dst;
@@ -908,6 +932,8 @@ int ctn_plan_step_info(const ctn_plan* plan, int step, ctn_step_info* info) {
   info->out_numel = plan->p.tensors[s.out].numel;
   info->tile_m = s.kernel == CTN_KERNEL_MFMA_F32 ? s.tileM : (s.kernel == CTN_KERNEL_MFMA_F64 ? kTile64M : 0);
   info->tile_n = (s.kernel == CTN_KERNEL_MFMA_F32 || s.kernel == CTN_KERNEL_MFMA_F64) ? s.tileN : 0;
+  info->epilogue_sum = s.epw;
+  info->reserved = 0;
   return CTN_OK;
 }
 

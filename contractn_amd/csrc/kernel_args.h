@@ -67,6 +67,9 @@ struct StepArgs {
   double numelA2;
   int32_t idA2, PA2, strideA2;
   int32_t krX, krY;   // modes 4 / 5: how each factor is read along the vector direction (0 gather, 1 float4, 2 broadcast)
+  // epilogue-summed GEMM (planner pattern C): extent (2 / 4) of the innermost column label that tensor idA2 -
+  // offsets of the rows in omA2, the label itself unit-stride - re-weights and sums on the way out; 0 = plain step
+  int32_t epw;
 };
 
 struct FinalArgs {

@@ -393,9 +393,13 @@ __device__ __forceinline__ void mfma_mainloop(typename LoaderOf<MA, BK, BM>::typ
 
 // second launch-bound argument = waves per SIMD the register allocator must leave room for:
 // BK = 16 is sized for 3 workgroups per CU (<= 168 registers), BK = 32 for 2
-template <int MA, int MB, int BK, int TN, int BM = kTileM>
+// EPW: the innermost column label (extent a.epw = 2 or 4, so the 4 columns a lane stores are whole groups of it) is
+// re-weighted by a third tensor W[row][p] and summed on the way out (planner pattern C: `bpr,bp->br` absorbed into
+// `bl,plr->bpr`); the C column table then repeats each output offset a.epw times.
+template <int MA, int MB, int BK, int TN, int BM = kTileM, bool EPW = false>
 __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a) {
   static_assert((BM == 128 || BM == 64) && (TN == 128 || TN == 64), "tile shapes");
+  static_assert(!EPW || (BM == 128 && MA <= 2), "epilogue-summed steps: 128-row tiles, plain A operand");
   using LA = typename LoaderOf<MA, BK, BM>::type;
   using LB = TileLoader<MB, BK, TN>;
   constexpr int SZA = LA::kSize, SZB = LB::kSize;
@@ -404,12 +408,13 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   // one LDS object: [A buf0][A buf1][B buf0][B buf1][omC BM][onC TN][red 4 doubles]; the operand buffers double as
   // the epilogue's per-wave staging area (32 rows x TN/2 columns each), which for the 64-row tile is the larger of the two
   constexpr int BUF = (2 * SZA + 2 * SZB > 4 * 32 * (TN / 2) ? 2 * SZA + 2 * SZB : 4 * 32 * (TN / 2) + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) float smem[BUF + BM + TN + 8];
+  __shared__ __attribute__((aligned(16))) float smem[BUF + BM + TN + 8 + (EPW ? BM : 0)];
   float* sA = smem;
   float* sB = smem + 2 * SZA;
   int* s_omC = reinterpret_cast<int*>(smem + BUF);
   int* s_onC = s_omC + BM;
   double* red = reinterpret_cast<double*>(s_onC + TN);
+  int* s_omW = reinterpret_cast<int*>(smem + BUF + BM + TN + 8);   // EPW: offset of every row in the weight tensor
 
   const int tid = threadIdx.x;
   // XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs, so give each
@@ -440,6 +445,13 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
 
   if (tid < BM) s_omC[tid] = a.omC[m0 + tid];
   else if (tid - BM < TN) s_onC[tid - BM] = a.onC[n0 + tid - BM];
+  float scW = 1.f;
+  const float* __restrict__ W = nullptr;
+  if constexpr (EPW) {
+    if (tid < BM) s_omW[tid] = a.omA2[m0 + tid];
+    scW = producer_scale<float>(a.partA2, a.PA2, a.strideA2, a.numelA2, a.min_norm, r);
+    W = (const float*)tp[a.idA2];
+  }
 
   LA la;
   LB lb;
@@ -505,7 +517,28 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
         const int lrow = it * RPI + lane / VW;
         const int row = wm + i * 32 + lrow;
         const float4 v = *reinterpret_cast<const float4*>(wC + lrow * WT + c4);
-        if (m0 + row < a.M && cin) {
+        if constexpr (EPW) {
+          if (m0 + row < a.M && cin) {
+            float* dst = C + s_omC[row];
+            const float* wp = W + s_omW[row];
+            const float iW = 1.0f / scW;
+            if (a.epw == 4) {
+              const float o = (v.x * (wp[0] * iW) + v.y * (wp[1] * iW)) + (v.z * (wp[2] * iW) + v.w * (wp[3] * iW));
+              dst[offn] = o;
+              asum += fabsf(o);
+            } else {
+              const float w0 = wp[0] * iW, w1 = wp[1] * iW;
+              const float o0 = v.x * w0 + v.y * w1;
+              dst[offn] = o0;
+              asum += fabsf(o0);
+              if (n0 + gcol + 2 < a.N) {
+                const float o1 = v.z * w0 + v.w * w1;
+                dst[s_onC[gcol + 2]] = o1;
+                asum += fabsf(o1);
+              }
+            }
+          }
+        } else if (m0 + row < a.M && cin) {
           float* dst = C + s_omC[row];
           if (a.c_vec) {
             *reinterpret_cast<float4*>(dst + offn) = v;

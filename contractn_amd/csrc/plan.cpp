@@ -166,13 +166,14 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
   // a GEMM whose result is only re-weighted and summed by a small tensor (`bl,plr->bpr` then `bpr,bp->br`: an MPS
   // site applied to a batch of inputs, reference paper Fig. 1d) is the same triple product regrouped (pattern B:
   // (v (.) x) . A).  Either way the intermediate - 4 GiB for CP with r = n = 1024 - never exists.  fp32 only (the
-  // KR loader lives in k_mfma_f32); CTN_FUSE=0 disables, 1 fuses whenever the pattern matches (tests).
+  // KR loader lives in k_mfma_f32); CTN_FUSE=0 disables, 1 fuses whenever a pattern matches (tests), 2 likewise but
+  // without pattern C below (so that pattern B can be tested on the networks C would take).
   // By default only intermediates of at least 2^28 elements (1 GiB) are fused away: the fused GEMM runs on the
   // register-staged kernel (a direct-to-LDS load cannot multiply), measured 13 % slower than materialising a 4 GiB
   // product and feeding the large-tile kernel (CP, r = n = 1024: 23.4 vs 20.7 ms) - a trade of time for memory that
   // only pays when the memory is large; at 2^31 elements it is the only way the step can run at all.
   constexpr double kFuseMinNumel = 268435456.0;
-  struct Fuse { int x = -1, y = -1, w = -1; };
+  struct Fuse { int x = -1, y = -1, w = -1; int epw = 0; int32_t pl = -1; };
   std::vector<Fuse> fuse(d.n_steps);
   std::vector<char> absorbed(d.n_steps, 0);
   {
@@ -203,6 +204,13 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
         return true;
       };
       auto ext = [&](int32_t l) { auto it = label_ext.find(l); return it == label_ext.end() ? (int64_t)1 : it->second; };
+      // is the last axis of network input `id` unit-stride?  (NULL strides = C-contiguous)
+      auto in_unit_last = [&](int id) {
+        if (!d.in_strides) return true;
+        int64_t c = 0;
+        for (int i = 0; i < id; ++i) c += d.in_ndim[i];
+        return d.in_ndim[id] > 0 && d.in_strides[c + d.in_ndim[id] - 1] == 1;
+      };
       std::vector<int> consumer(nt, -1);
       for (int s = 0; s < d.n_steps; ++s) {
         if (d.step_lhs[s] >= 0 && d.step_lhs[s] < nt) consumer[d.step_lhs[s]] = s;
@@ -235,7 +243,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
           bool k2 = false;
           for (int id : {t1, other}) for (int32_t l : labs[id]) if (!has(out2, l)) k2 = true;
           const bool big = numel[t1] >= kFuseMinNumel && numel[t1] >= 8.0 * (numel[p] + numel[q]);
-          if (k2 && gemm_ok(p, q, other, out2) && (fmode == 1 || big)) {
+          if (k2 && gemm_ok(p, q, other, out2) && (fmode >= 1 || big)) {
             // X = the factor with the larger stride pattern first is irrelevant: keep (p, q)
             fuse[s2].x = p; fuse[s2].y = q; fuse[s2].w = other; absorbed[s1] = 1;
           }
@@ -244,8 +252,49 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
           bool sub = true;
           for (int32_t l : labs[other]) if (!has(t1, l)) sub = false;
           if (!sub) continue;
+          // pattern C first: `other` is a network input that sums ONE short label (extent 2 or 4, its own unit-stride
+          // axis) which the GEMM keeps as a column label, while everything else it carries are row labels of the
+          // GEMM: the GEMM runs as it is, with that label innermost among its columns, and the re-weighting and the
+          // short sum happen on the accumulator tile in the epilogue - X = E . A never reaches memory and the
+          // streaming step is gone (batched MPS site, B = 4096, D = 256: 30.6 + 10.9 us -> see DESIGN.md)
+          if (fmode != 2) {
+            int32_t pl = -1;
+            int nsum = 0;
+            for (int32_t l : labs[t1]) if (!has(out2, l)) { ++nsum; pl = l; }
+            bool okc = nsum == 1 && has(other, pl) && (ext(pl) == 2 || ext(pl) == 4) && other < d.n_inputs &&
+                       !labs[other].empty() && labs[other].back() == pl && in_unit_last(other);
+            int opA = -1, opB = -1;
+            if (okc) {
+              if (has(q, pl) && !has(p, pl)) { opA = p; opB = q; }
+              else if (has(p, pl) && !has(q, pl)) { opA = q; opB = p; }
+              else okc = false;
+            }
+            if (okc)
+              for (int32_t l : labs[other])
+                if (l != pl && !(has(opA, l) && !has(opB, l) && has(out2, l))) okc = false;
+            if (okc) {
+              // the GEMM itself: rows from opA only, columns from opB only (pl among them), something summed
+              int64_t M = 1, N = 1, K = 1, Bt = 1;
+              std::vector<int32_t> all;
+              for (int id : {opA, opB}) for (int32_t l : labs[id]) if (std::find(all.begin(), all.end(), l) == all.end()) all.push_back(l);
+              for (int32_t l : all) {
+                const bool inA = has(opA, l), inB = has(opB, l), inC = has(t1, l);
+                if (!inC) K *= ext(l);
+                else if (inA && inB) Bt *= ext(l);
+                else if (inA) M *= ext(l);
+                else N *= ext(l);
+              }
+              okc = M >= 64 && N >= 32 && K >= 8 && M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31) &&
+                    (double)Bt * (double)M * (double)N >= 65536.0;
+            }
+            if (okc) {
+              fuse[s2].x = opA; fuse[s2].y = other; fuse[s2].w = opB; fuse[s2].epw = (int)ext(pl); fuse[s2].pl = pl;
+              absorbed[s1] = 1;
+              continue;
+            }
+          }
           const bool big = numel[t1] >= kFuseMinNumel && numel[t1] >= 4.0 * numel[out2] && numel[other] * 16.0 <= numel[t1];
-          if (!(fmode == 1 || big)) continue;
+          if (!(fmode >= 1 || big)) continue;
           // `other` joins the side that carries more of its kept labels
           int kp = 0, kq = 0;
           for (int32_t l : labs[other]) if (has(out2, l)) { kp += has(p, l); kq += has(q, l); }
@@ -304,8 +353,9 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       P.steps.push_back(std::move(st));
       continue;
     }
-    const bool fused = fuse[s].x >= 0;
-    if (fused) { lhs = fuse[s].x; rhs = fuse[s].w; }   // A = X (.) Y (Y = fuse[s].y), B = W
+    const int epw = fuse[s].epw;                          // pattern C: re-weighted short sum in the epilogue
+    const bool fused = fuse[s].x >= 0 && !epw;            // patterns A / B: A = X (.) Y (Y = fuse[s].y), B = W
+    if (fuse[s].x >= 0) { lhs = fuse[s].x; rhs = fuse[s].w; }
 
     // -- label census
     std::vector<LabelInfo> info;
@@ -313,7 +363,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       for (auto& l : info) if (l.label == lab) return &l;
       return nullptr;
     };
-    auto scan = [&](const Tensor& T, int which /*0 A (X), 1 B, 2 second A-side tensor Y*/) {
+    auto scan = [&](const Tensor& T, int which /*0 A (X), 1 B, 2 second A-side tensor Y, 3 epilogue weights*/) {
       for (size_t a = 0; a < T.labels.size(); ++a) {
         LabelInfo* l = find(T.labels[a]);
         if (!l) {
@@ -324,6 +374,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
           l->firstPos = (int)info.size();
         }
         (which == 0 ? l->sA : which == 1 ? l->sB : l->sA2) += T.strides[a];  // repeated label = diagonal: strides add
+        if (which == 3) { l->inA2 = true; continue; }   // the epilogue's weight tensor: strides only, no class
         if (which == 1) l->inB = true; else l->inA = true;
         if (which == 0) l->inX = true;
         if (which == 2) l->inA2 = true;
@@ -332,6 +383,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     scan(P.tensors[lhs], 0);
     if (fused) scan(P.tensors[fuse[s].y], 2);
     if (rhs >= 0) scan(P.tensors[rhs], 1);
+    if (epw) scan(P.tensors[fuse[s].y], 3);
     for (size_t a = 0; a < out_labels.size(); ++a) {
       LabelInfo* l = find(out_labels[a]);
       if (!l) { err = fmt("step %lld: output label %lld is in neither operand", s, out_labels[a]); return CTN_INVALID_ARG; }
@@ -339,9 +391,11 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       l->inC = true;
     }
 
+    if (epw) find(fuse[s].pl)->inC = true;   // a column label of the GEMM (summed later, in the epilogue; sC stays 0)
+
     // -- operand swap: the output's unit-stride label should be a column (N) label
     bool swap = false;
-    if (rhs >= 0 && !fused) {   // (the on-the-fly product can only be the A operand)
+    if (rhs >= 0 && !fused && !epw) {   // (the on-the-fly product can only be the A operand; pattern C fixed the sides)
       if (last) {
         if (!out_labels.empty()) {
           LabelInfo* l = find(out_labels.back());
@@ -358,7 +412,8 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       for (auto& l : info) { std::swap(l.sA, l.sB); std::swap(l.inA, l.inB); }
     }
     st.lhs = lhs; st.rhs = rhs; st.out = out_id; st.swapped = swap;
-    st.lhs2 = fused ? fuse[s].y : -1;
+    st.lhs2 = fused || epw ? fuse[s].y : -1;
+    st.epw = epw;
 
     // -- classify and order
     std::vector<LabelInfo*> G[4];
@@ -378,6 +433,12 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     std::stable_sort(G[kBatch].begin(), G[kBatch].end(), by(true));
     std::stable_sort(G[kM].begin(), G[kM].end(), by(true));
     std::stable_sort(G[kN].begin(), G[kN].end(), by(false));
+    if (epw) {   // the label summed in the epilogue is the innermost column label: four adjacent columns = its values
+      auto it = std::find(G[kN].begin(), G[kN].end(), find(fuse[s].pl));
+      LabelInfo* pl = *it;
+      G[kN].erase(it);
+      G[kN].push_back(pl);
+    }
     bool aUnitInK = false, bUnitInK = false;
     for (auto* l : G[kK]) { if (l->inA && l->sA == 1) aUnitInK = true; if (l->inB && l->sB == 1) bUnitInK = true; }
     // k order = memory order of the operand that is unit-stride along a contracted label; when both are, but along
@@ -393,7 +454,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     if (last) {
       out.labels = out_labels;
     } else {
-      for (int c : {kBatch, kM, kN}) for (auto* l : G[c]) out.labels.push_back(l->label);
+      for (int c : {kBatch, kM, kN}) for (auto* l : G[c]) if (!epw || l->label != fuse[s].pl) out.labels.push_back(l->label);
     }
     for (int32_t lab : out.labels) out.dims.push_back(find(lab)->ext);
     out.strides.assign(out.labels.size(), 1);
@@ -479,7 +540,11 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       // blocks / partial slots stay counted in 128 x 128 units.
       const int64_t pad128 = round_up(st.M, kTileM) * round_up(st.N, kTileN);
       const int64_t pad256 = round_up(st.M, 256) * round_up(st.N, kTileN);
-      if (!fused && st.modeA >= 1 && st.modeB >= 1 && st.tileN == kTileN && st.cvec && st.K >= 32 &&
+      if (epw) {   // epilogue-summed steps: 128-row tiles of the register-staged kernel only
+        st.tileM = kTileM;
+        st.blocks = (int)(st.Bt * ((st.M + st.tileM - 1) / st.tileM) * ((st.N + st.tileN - 1) / st.tileN));
+      }
+      if (!fused && !epw && st.modeA >= 1 && st.modeB >= 1 && st.tileN == kTileN && st.cvec && st.K >= 32 &&
           st.M > kTileM && pad256 * 100 <= pad128 * 115 &&
           st.rhs >= 0 && P.tensors[st.lhs].numel <= (1LL << 30) && P.tensors[st.rhs].numel <= (1LL << 30)) {  // 32-bit byte offsets
         st.tileM = 256;
@@ -567,14 +632,15 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
         st.blocks = stream_grid((items + 255) / 256);
       }
     }
-    st.chain_ok = outs <= kChainMaxOut && outs * st.K <= kChainMaxWork;
+    st.chain_ok = outs <= kChainMaxOut && outs * st.K <= kChainMaxWork && !epw;
     st.collapse = st.blocks > kMaxPartials;
     st.partials = st.collapse ? 1 : st.blocks;
     // (x2: the launcher may halve the column tile of an under-filled fp32 MFMA launch)
     if (st.collapse) P.max_collapse_blocks = std::max<int64_t>(P.max_collapse_blocks, 2 * (int64_t)st.blocks);
     st.flops = (st.has_k ? 2.0 : 1.0) * (double)st.Bt * (double)st.M * (double)st.N * (double)st.K +
                (P.stabilize ? 3.0 * (double)out.numel : 0.0) +
-               (fused ? (double)st.Bt * (double)st.M * (double)st.K : 0.0);   // the multiplies of the fused product
+               (fused ? (double)st.Bt * (double)st.M * (double)st.K : 0.0) +   // the multiplies of the fused product
+               (epw ? 2.0 * (double)st.Bt * (double)st.M * (double)st.N : 0.0);  // the re-weighting and the short sum
     P.flops += st.flops;
 
     // -- gather-offset tables
@@ -598,6 +664,9 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       build_table(gb, 3, st.Bt, tb); st.t.obA2 = append(P.tables, tb);
       build_table(gm, 3, padM, tb);  st.t.omA2 = append(P.tables, tb);
       build_table(gk, 3, padK, tb);  st.t.okA2 = append(P.tables, tb);
+    }
+    if (epw) {     // the epilogue's weights: offset of every row (their short label is unit-stride: + p)
+      build_table(gm, 3, padM, tb);  st.t.omA2 = append(P.tables, tb);
     }
 
     // -- workspace: allocate the output, then release the consumed intermediates

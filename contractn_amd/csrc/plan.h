@@ -53,6 +53,8 @@ struct Step {
   int lhs = -1, rhs = -1, out = -1;  // tensor ids after the optional operand swap; rhs -1 = unary
   int lhs2 = -1;         // fused steps: A = tensors[lhs] (.) tensors[lhs2], formed on the fly (modeA 3, 4, 5)
   int krX = 0, krY = 0;  // modeA 4 / 5: how each factor is read along the vector direction (0 gather, 1 float4, 2 broadcast)
+  int epw = 0;           // 2 / 4: the step is a GEMM whose innermost column label (this extent) is re-weighted by
+                         // tensors[lhs2] and summed in the epilogue ("bl,plr->bpr" then "bpr,bp->br" as one step)
   bool swapped = false;
   int kernel = CTN_KERNEL_ELEMENT;
   int64_t Bt = 1, M = 1, N = 1, K = 1;

@@ -72,10 +72,15 @@ int main() {
       const int64_t a_max = maxof(st.t.obA, st.Bt) + maxof(st.t.omA, st.M) + maxof(st.t.okA, st.K);
       const int64_t c_max = maxof(st.t.obC, st.Bt) + maxof(st.t.omC, st.M) + maxof(st.t.onC, st.N);
       if (a_max >= P.tensors[st.lhs].numel || c_max >= P.tensors[st.out].numel) ok = false;
-      if (st.lhs2 >= 0) {   // fused step: the second tensor of the A side
+      if (st.lhs2 >= 0 && !st.epw) {   // fused step: the second tensor of the A side
         const int64_t a2_max = maxof(st.t.obA2, st.Bt) + maxof(st.t.omA2, st.M) + maxof(st.t.okA2, st.K);
         if (a2_max >= P.tensors[st.lhs2].numel) ok = false;
       }
+      if (st.epw) {   // epilogue weights: row offset + the short label's values (unit-stride)
+        if (maxof(st.t.omA2, st.M) + st.epw - 1 >= P.tensors[st.lhs2].numel || st.N % st.epw != 0) ok = false;
+        if (P.tensors[st.out].numel * st.epw != st.Bt * st.M * st.N) ok = false;
+      }
+      h = mix(h, (uint64_t)st.epw);
       if (st.rhs >= 0) {
         const int64_t b_max = maxof(st.t.obB, st.Bt) + maxof(st.t.onB, st.N) + maxof(st.t.okB, st.K);
         if (b_max >= P.tensors[st.rhs].numel) ok = false;

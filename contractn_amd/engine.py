@@ -75,6 +75,8 @@ class StepInfo(C.Structure):
         ("out_numel", C.c_int64),
         ("tile_m", C.c_int32),
         ("tile_n", C.c_int32),
+        ("epilogue_sum", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

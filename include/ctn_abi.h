@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CTN_ABI_VERSION 1
+#define CTN_ABI_VERSION 2
 
 typedef enum {
   CTN_OK = 0,
@@ -110,6 +110,10 @@ typedef struct {
   int64_t out_numel;
   int32_t tile_m;      /* MFMA steps: workgroup tile rows (fp32: 128, or 256 = LDS-DMA large-tile kernel); else 0 */
   int32_t tile_n;      /* MFMA steps: workgroup tile columns (fp32: 128 / 64, fp64: 64); else 0 */
+  int32_t epilogue_sum; /* 2 / 4: the step's GEMM keeps one more (innermost) column label of this extent, which a third
+                           tensor - a network input - re-weights and sums on the accumulator tile (an absorbed
+                           `bpr,bp->br` after `bl,plr->bpr`: n counts the label, out_numel does not); else 0 */
+  int32_t reserved;
 } ctn_step_info;
 
 /* ---- library ---------------------------------------------------------- */

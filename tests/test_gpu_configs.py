@@ -70,7 +70,9 @@ def test_cfg3b_batched_inputs_through_batch_hyperedge():
     assert max(i["out_numel"] for i in plan.step_infos()) <= B * bond * phys
     infos = plan.step_infos()
     assert any(i["kernel"] == 2 and B in (i["m"], i["n"]) for i in infos)      # GEMM with M = batch
-    assert sum(i["batch"] == B for i in infos) >= n_sites - 1                   # hyperedge steps
+    # hyperedge steps: their own launches (batch label = B), or - the interior sites - folded into the GEMM's epilogue
+    assert sum(i["batch"] == B or i["epilogue_sum"] == phys for i in infos) >= n_sites - 1
+    assert sum(i["epilogue_sum"] == phys for i in infos) == n_sites - 2
 
 
 def test_cfg4_cp_hyperedge_equals_tucker_with_delta_hub():

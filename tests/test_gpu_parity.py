@@ -746,7 +746,17 @@ def test_fused_product_as_gemm_operand_vs_numpy(einstr, shapes, path, force_fusi
     assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-5
 
 
-def test_fused_gemm_with_reweighting_consumer_batched_mps(force_fusion):
+@pytest.fixture
+def force_fusion_kr(monkeypatch):
+    """CTN_FUSE=2: every Khatri-Rao pattern forced, the epilogue-sum pattern (which would take the batched-MPS sites
+    first) off."""
+    monkeypatch.setenv("CTN_FUSE", "2")
+    E.clear_caches()
+    yield
+    E.clear_caches()
+
+
+def test_fused_gemm_with_reweighting_consumer_batched_mps(force_fusion_kr):
     """Pattern B: an MPS site applied to a batch of inputs - `bl,plr->bpr` then `bpr,bp->br` - runs as ONE GEMM over
     (p, l) whose A operand v[b,l] * x[b,p] is formed on the fly; v is a rescaled intermediate of the previous site.
     Against the oracle on the same path (the oracle materialises every intermediate)."""
@@ -773,6 +783,78 @@ def test_fused_gemm_with_reweighting_consumer_batched_mps(force_fusion):
     # replicas in flight and the unfused plan give the same numbers to rounding
     t2, c2 = fun(tn.params, inputs)
     assert np.array_equal(t2, t) and float(c2) == float(c)
+
+
+# ---- pattern C: a short label re-weighted by a network input and summed in the GEMM's epilogue ----------------------
+@pytest.mark.parametrize("einstr,shapes", [
+    ("bl,plr,bp->br", [(256, 64), (4, 64, 64), (256, 4)]),          # one batched-MPS site, d = 4
+    ("bl,plr,bp->br", [(1200, 40), (2, 40, 33), (1200, 2)]),        # d = 2, ragged rows, N = 66 (half a vector at the edge)
+    ("bl,plr,bp->br", [(390, 24), (4, 24, 50), (390, 4)]),          # d = 4, ragged rows and columns
+    ("bl,lrp,bp->br", [(256, 32), (32, 64, 4), (256, 4)]),          # the short label innermost in the core too
+    ("xbl,xplr,bp->xbr", [(3, 128, 16), (3, 4, 16, 64), (128, 4)]), # a batch label the weights do not carry
+    ("bl,plr,bp->rb", [(256, 64), (4, 64, 64), (256, 4)]),          # last step, caller's axis order
+    ("abl,plr,abp->abr", [(16, 32, 48), (2, 48, 64), (16, 32, 2)]), # two row labels in the weights
+])
+def test_epilogue_sum_step_vs_numpy(einstr, shapes):
+    rng = np.random.default_rng(23)
+    ops = [(rng.standard_normal(s) * rng.uniform(0.5, 2.0)).astype(np.float32) for s in shapes]
+    path = ((0, 1), (0, 1))
+    E.clear_caches()
+    infos = _fused_infos(einstr, shapes, path)
+    ext_p = shapes[2][-1]
+    assert [i["kernel"] for i in infos] == [5, 2] and infos[1]["epilogue_sum"] == ext_p, infos
+    assert infos[1]["out_numel"] * ext_p == infos[1]["batch"] * infos[1]["m"] * infos[1]["n"]
+    t_hat, c = contract(einstr, *ops, optimize=path, split_format=True)
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    got = t_hat.astype(np.float64) * np.exp(float(c))
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 2e-4 * np.max(np.abs(ref))
+    assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-5
+    E.clear_caches()
+
+
+def test_epilogue_sum_batched_mps_vs_oracle_and_vs_unfused(monkeypatch):
+    """The paper's ML workload (reference README, Fig. 1d): every interior site of a batched MPS evaluation is ONE
+    launch - `bl,plr->bpr` with `bpr,bp->br` folded into its epilogue; the (B, d, D) tensor never exists.  Against the
+    oracle on the same path, against the unfused plan, with replicas in flight, and twice for bit-identity."""
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from oracle import cpu_ref
+    from tests import networks as nets
+
+    monkeypatch.delenv("CTN_FUSE", raising=False)
+    E.clear_caches()
+    B, n_sites, bond, phys = 256, 6, 64, 4
+    tn, inputs = nets.batched_mps(TN, n_sites, bond, phys, B, dtype=np.float32, seed=4)
+    path = ssa_to_linear(nets.batched_mps_path(n_sites), 2 * n_sites)
+    ops = E.make_arg_packer(tn)(tn.params, inputs)
+    shapes = [o.shape for o in ops]
+    infos = _fused_infos(tn.einsum_str, shapes, path)
+    assert sum(i["kernel"] == 5 for i in infos) == n_sites - 2 == sum(i["epilogue_sum"] == phys for i in infos), infos
+    assert max(i["out_numel"] for i in infos if i["kernel"] != 5) <= B * bond
+    fun = tn.make_contract_fun(optimize=path, split_format=True)
+    t, c = fun(tn.params, inputs)
+    clist = E._contract_path(tn.einsum_str, tuple(shapes), optimize=path, memory_limit=None, use_blas=True)
+    rt, rc, _ = cpu_ref.core_contract(list(ops), clist)
+    got = t.astype(np.float64) * np.exp(float(c))
+    ref = np.asarray(rt, dtype=np.float64) * np.exp(float(rc))
+    assert np.max(np.abs(got - ref)) <= 1e-3 * np.max(np.abs(ref))
+    t2, c2 = fun(tn.params, inputs)
+    assert np.array_equal(t2, t) and float(c2) == float(c)
+    # three replicas of the plan in one launch: replica 0 carries the same operands
+    bc = E.BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=3)
+    rng = np.random.default_rng(5)
+    reps = [list(ops)] + [[(o * rng.uniform(0.5, 1.5)).astype(np.float32) for o in ops] for _ in range(2)]
+    tb, cb = bc.run_host(reps)
+    assert np.array_equal(tb[0], t) and float(cb[0]) == float(c)
+    # the unfused plan: same numbers to rounding
+    monkeypatch.setenv("CTN_FUSE", "0")
+    E.clear_caches()
+    assert all(i["kernel"] != 5 for i in _fused_infos(tn.einsum_str, shapes, path))
+    t0, c0 = tn.make_contract_fun(optimize=path, split_format=True)(tn.params, inputs)
+    un = t0.astype(np.float64) * np.exp(float(c0))
+    assert np.max(np.abs(got - un)) <= 1e-5 * np.max(np.abs(un))
+    E.clear_caches()
 
 
 def test_fusion_is_off_for_small_intermediates_and_switchable(monkeypatch):
