@@ -103,12 +103,18 @@ __device__ __forceinline__ T producer_scale(const double* part, int P, int strid
   // lane l adds partials l, l + 64, ... (P <= kMaxPartials: at most 8 loads), then the xor butterfly: a fixed order
   const double* __restrict__ pr = part + (size_t)r * stride;
   double v = 0.0;
-  int i = lane;
-  for (; i + 192 < P; i += 256) {   // four independent loads in flight; added in index order as the plain loop does
-    const double d0 = pr[i], d1 = pr[i + 64], d2 = pr[i + 128], d3 = pr[i + 192];
-    v += d0; v += d1; v += d2; v += d3;
+  if (P <= 64) {
+    if (lane < P) v = pr[lane];
+  } else {
+    // all of a lane's (at most 8) partials requested at once - one memory latency, not one per round - and added in
+    // index order as a plain loop would (an absent one reads the last slot and counts as +0.0: abs-sums are >= 0)
+    const int n4 = P <= 256 ? 4 : 8;
+    double d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = j < n4 ? pr[min(lane + 64 * j, P - 1)] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += (lane + 64 * j < P) ? d[j] : 0.0;
   }
-  for (; i < P; i += 64) v += pr[i];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   const T norm = (T)v;

@@ -408,13 +408,14 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   // one LDS object: [A buf0][A buf1][B buf0][B buf1][omC BM][onC TN][red 4 doubles]; the operand buffers double as
   // the epilogue's per-wave staging area (32 rows x TN/2 columns each), which for the 64-row tile is the larger of the two
   constexpr int BUF = (2 * SZA + 2 * SZB > 4 * 32 * (TN / 2) ? 2 * SZA + 2 * SZB : 4 * 32 * (TN / 2) + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) float smem[BUF + BM + TN + 8 + (EPW ? BM : 0)];
+  __shared__ __attribute__((aligned(16))) float smem[BUF + BM + TN + 8 + (EPW ? 5 * BM : 0)];
   float* sA = smem;
   float* sB = smem + 2 * SZA;
   int* s_omC = reinterpret_cast<int*>(smem + BUF);
   int* s_onC = s_omC + BM;
   double* red = reinterpret_cast<double*>(s_onC + TN);
   int* s_omW = reinterpret_cast<int*>(smem + BUF + BM + TN + 8);   // EPW: offset of every row in the weight tensor
+  float* s_W = smem + BUF + BM + TN + 8 + BM;                      // EPW: [BM][4] the rows' weights, rescaled
 
   const int tid = threadIdx.x;
   // XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs, so give each
@@ -433,11 +434,6 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 0] = __builtin_amdgcn_s_memtime();
 #endif
-  float scA = producer_scale<float>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
-  const float scB = producer_scale<float>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
-  float scA2 = 1.f;
-  if constexpr (MA >= 3) scA2 = producer_scale<float>(a.partA2, a.PA2, a.strideA2, a.numelA2, a.min_norm, r);
-
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
   const float* __restrict__ B = (const float*)tp[a.idB] + a.obB[b];
@@ -459,6 +455,12 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   if constexpr (MA == 3) la.init2(a.omA2, a.okA2, (const float*)tp[a.idA2] + a.obA2[b], m0, tid);
   if constexpr (MA >= 4) la.init2(a.omA2, a.okA2, (const float*)tp[a.idA2] + a.obA2[b], m0, tid, a.krX, a.krY);
   lb.init(a.onB, n0, a.N, tid);
+  // the producers' partial sums are requested AFTER the offset tables, so one wait covers both (their reduction is a
+  // wave butterfly: asked for first, its wait used to hold back the table loads - 512 partials, two rounds: ~1 us)
+  float scA = producer_scale<float>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
+  const float scB = producer_scale<float>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
+  float scA2 = 1.f;
+  if constexpr (MA >= 3) scA2 = producer_scale<float>(a.partA2, a.PA2, a.strideA2, a.numelA2, a.min_norm, r);
 
   const int lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * (BM / 2), wn = (w & 1) * (TN / 2);
@@ -489,6 +491,19 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   // (KR: both factors of the A operand carry a rescale; folded into one multiplier)
   const float iA = MA >= 3 ? (1.0f / scA) * (1.0f / scA2) : 1.0f / scA, iB = 1.0f / scB;
   float asum = 0.f;
+  if constexpr (EPW) {
+    // the tile's weights through LDS, fetched once (read from memory inside the store loop below, every one of its
+    // eight rounds waited for its own loads: 4.2 us of epilogue on a 128 x 64 x 256 tile)
+    if (tid < BM && m0 + tid < a.M) {
+      const float* wp = W + s_omW[tid];
+      const float iW = 1.0f / scW;
+      const float w0 = wp[0], w1 = wp[1];
+      float w2 = 0.f, w3 = 0.f;
+      if (a.epw == 4) { w2 = wp[2]; w3 = wp[3]; }
+      *reinterpret_cast<float4*>(s_W + 4 * tid) = make_float4(w0 * iW, w1 * iW, w2 * iW, w3 * iW);
+    }
+    __syncthreads();
+  }
   {
     // Each WAVE stages its own 64 x TN/2 accumulator block through its quarter of the (now idle)
     // operand buffers, 32 rows at a time, and stores whole 16-byte row segments (4-8 rows of
@@ -520,14 +535,13 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
         if constexpr (EPW) {
           if (m0 + row < a.M && cin) {
             float* dst = C + s_omC[row];
-            const float* wp = W + s_omW[row];
-            const float iW = 1.0f / scW;
+            const float4 wv = *reinterpret_cast<const float4*>(s_W + 4 * row);
             if (a.epw == 4) {
-              const float o = (v.x * (wp[0] * iW) + v.y * (wp[1] * iW)) + (v.z * (wp[2] * iW) + v.w * (wp[3] * iW));
+              const float o = (v.x * wv.x + v.y * wv.y) + (v.z * wv.z + v.w * wv.w);
               dst[offn] = o;
               asum += fabsf(o);
             } else {
-              const float w0 = wp[0] * iW, w1 = wp[1] * iW;
+              const float w0 = wv.x, w1 = wv.y;
               const float o0 = v.x * w0 + v.y * w1;
               dst[offn] = o0;
               asum += fabsf(o0);
