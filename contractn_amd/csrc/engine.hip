@@ -46,6 +46,7 @@ struct DevSwitches {
   int mfma_g = 1;        // CTN_MFMA_G: 0 never use the large-tile LDS-DMA kernels, 1 when a launch fills the chip, 2 whenever eligible (tests)
   int graph = 1;         // CTN_GRAPH=0: every enqueue issues its launches one by one
   int mfma_bk = 0;       // CTN_MFMA_BK=16|32: force the k-tile depth of k_mfma_f32
+  int halve = 1;         // CTN_HALVE_TILES=0: never halve the tiles of an under-filled register-staged launch
   int lat64_min_k = 512; // CTN_LAT64_MIN_K: least K for the 64 x 64 one-launch latency form when an operand is k-contiguous
   int splitk = -1;       // CTN_SPLITK: 0 disables the latency mode, 1 forces it for every eligible step (tests)
   int splitk_max = 0;    // CTN_SPLITK_MAX: tile-count threshold of the latency mode
@@ -65,6 +66,7 @@ static DevSwitches read_dev_switches() {
   d.splitk_max = num("CTN_SPLITK_MAX", 0);
   d.lat = num("CTN_LAT", -1);
   d.lat64_min_k = num("CTN_LAT64_MIN_K", 512);
+  d.halve = num("CTN_HALVE_TILES", 1);
   d.g_no_asm = getenv("CTN_G_NO_ASM") != nullptr;
   d.stamps = getenv("CTN_DEBUG_STAMPS");
   d.stamp_step = num("CTN_DEBUG_STAMP_STEP", -1);
@@ -186,21 +188,21 @@ static void launch_mfma_a(int ma, int mb, dim3 grid, hipStream_t st, const StepA
   }
 }
 
-// epilogue-summed steps (planner pattern C): 128-row tiles, BK = 16, a plain A operand
-template <int MA, int TN>
+// epilogue-summed steps (planner pattern C): BK = 16, a plain A operand
+template <int MA, int TN, int TM>
 static void launch_mfma_epw_b(int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
   switch (mb) {
-    case 1: hipLaunchKernelGGL((k_mfma_f32<MA, 1, 16, TN, 128, true>), grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((k_mfma_f32<MA, 2, 16, TN, 128, true>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((k_mfma_f32<MA, 0, 16, TN, 128, true>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((k_mfma_f32<MA, 1, 16, TN, TM, true>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_mfma_f32<MA, 2, 16, TN, TM, true>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_mfma_f32<MA, 0, 16, TN, TM, true>), grid, dim3(256), 0, st, a); break;
   }
 }
-template <int TN>
+template <int TN, int TM>
 static void launch_mfma_epw(int ma, int mb, dim3 grid, hipStream_t st, const StepArgs& a) {
   switch (ma) {
-    case 1: launch_mfma_epw_b<1, TN>(mb, grid, st, a); break;
-    case 2: launch_mfma_epw_b<2, TN>(mb, grid, st, a); break;
-    default: launch_mfma_epw_b<0, TN>(mb, grid, st, a); break;
+    case 1: launch_mfma_epw_b<1, TN, TM>(mb, grid, st, a); break;
+    case 2: launch_mfma_epw_b<2, TN, TM>(mb, grid, st, a); break;
+    default: launch_mfma_epw_b<0, TN, TM>(mb, grid, st, a); break;
   }
 }
 
@@ -216,8 +218,13 @@ static int mfma_bk(int K, const DevSwitches& sw) {
 // tile_m = 64: skinny rows (M <= 64 against a huge N) - always BK = 16 (these steps have a short K)
 static void launch_mfma(int ma, int mb, int tile_m, int tile_n, dim3 grid, hipStream_t st, const StepArgs& a, const DevSwitches& sw) {
   if (a.epw) {
-    if (tile_n == 64) launch_mfma_epw<64>(ma, mb, grid, st, a);
-    else launch_mfma_epw<128>(ma, mb, grid, st, a);
+    if (tile_m == 64) {
+      if (tile_n == 64) launch_mfma_epw<64, 64>(ma, mb, grid, st, a);
+      else launch_mfma_epw<128, 64>(ma, mb, grid, st, a);
+    } else {
+      if (tile_n == 64) launch_mfma_epw<64, 128>(ma, mb, grid, st, a);
+      else launch_mfma_epw<128, 128>(ma, mb, grid, st, a);
+    }
     return;
   }
   const bool bk16 = mfma_bk(a.K, sw) == 16;
@@ -294,10 +301,10 @@ static bool g_launch(const Step& st, int R, int n_cu, int use_g) {
   return use_g >= 2 || (gtiles >= 2LL * n_cu && st.K >= 192) || (st.K >= 1024 && 4 * gtiles >= 3LL * n_cu);
 }
 
-static void plain_tiles(const Step& st, int R, int n_cu, int use_g, bool is_last, int* tm, int* tn) {
+static void plain_tiles(const Step& st, int R, int n_cu, int use_g, bool is_last, int* tm, int* tn, int halve = 1) {
   *tm = st.tileM == 64 ? 64 : kTileM;
   *tn = st.tileN;
-  if (st.kernel != CTN_KERNEL_MFMA_F32 || st.collapse) return;
+  if (st.kernel != CTN_KERNEL_MFMA_F32 || st.collapse || !halve) return;
   // a step the planner made eligible for the large-tile kernel keeps 128-unit counting when that kernel will (or,
   // for the caller's possibly unaligned final buffer, may) take it
   if (st.tileM == 256 && (is_last || g_launch(st, R, n_cu, use_g))) return;
@@ -306,7 +313,7 @@ static void plain_tiles(const Step& st, int R, int n_cu, int use_g, bool is_last
     int a = *tm, b = *tn;
     // columns first: 128 x 64 tiles measured 62 vs 45 TFLOP/s for 64 x 128 on 4096 x 1024 x 256 (one batched-MPS site)
     if (b == 128 && st.N > 64) b = 64;
-    else if (a == 128 && st.M > 64 && !st.epw) a = 64;   // (epilogue-summed steps exist for 128-row tiles only)
+    else if (a == 128 && st.M > 64) a = 64;
     else break;
     if (tiles(a, b) > 4096) break;
     *tm = a; *tn = b;
@@ -570,7 +577,7 @@ static int exec_launch_steps(Exec* E) {
         }
         // register-staged tiles; halved (128 -> 64 rows / columns) while the launch is under-filled - see plain_tiles
         int tm = row_tile, tn = st.tileN;
-        plain_tiles(st, R, E->n_cu, E->mfma_g, s + 1 == P.n_steps, &tm, &tn);
+        plain_tiles(st, R, E->n_cu, E->mfma_g, s + 1 == P.n_steps, &tm, &tn, E->sw.halve);
         a.tiles_m = (int32_t)((st.M + tm - 1) / tm);
         a.tiles_n = (int32_t)((st.N + tn - 1) / tn);
         a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
@@ -1009,7 +1016,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
       E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kWaveOutputs, P.tensors[st.out].numel / 1024));
     else if (st.kernel == CTN_KERNEL_MFMA_F32 && !st.collapse) {
       int tm, tn;
-      plain_tiles(st, replicas, E.n_cu, E.mfma_g, s + 1 == P.n_steps, &tm, &tn);
+      plain_tiles(st, replicas, E.n_cu, E.mfma_g, s + 1 == P.n_steps, &tm, &tn, E.sw.halve);
       const int64_t tiles = st.Bt * ((st.M + tm - 1) / tm) * ((st.N + tn - 1) / tn);
       E.step_partials[s] = tiles > kMaxPartials ? 1 : (int)tiles;     // halved tiles beyond the slots: collapsed at launch
       scratch_need = std::max<int64_t>(scratch_need, tiles);

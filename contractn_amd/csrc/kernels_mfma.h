@@ -399,7 +399,7 @@ __device__ __forceinline__ void mfma_mainloop(typename LoaderOf<MA, BK, BM>::typ
 template <int MA, int MB, int BK, int TN, int BM = kTileM, bool EPW = false>
 __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a) {
   static_assert((BM == 128 || BM == 64) && (TN == 128 || TN == 64), "tile shapes");
-  static_assert(!EPW || (BM == 128 && MA <= 2), "epilogue-summed steps: 128-row tiles, plain A operand");
+  static_assert(!EPW || MA <= 2, "epilogue-summed steps: plain A operand");
   using LA = typename LoaderOf<MA, BK, BM>::type;
   using LB = TileLoader<MB, BK, TN>;
   constexpr int SZA = LA::kSize, SZB = LB::kSize;

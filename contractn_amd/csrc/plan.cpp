@@ -540,10 +540,6 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       // blocks / partial slots stay counted in 128 x 128 units.
       const int64_t pad128 = round_up(st.M, kTileM) * round_up(st.N, kTileN);
       const int64_t pad256 = round_up(st.M, 256) * round_up(st.N, kTileN);
-      if (epw) {   // epilogue-summed steps: 128-row tiles of the register-staged kernel only
-        st.tileM = kTileM;
-        st.blocks = (int)(st.Bt * ((st.M + st.tileM - 1) / st.tileM) * ((st.N + st.tileN - 1) / st.tileN));
-      }
       if (!fused && !epw && st.modeA >= 1 && st.modeB >= 1 && st.tileN == kTileN && st.cvec && st.K >= 32 &&
           st.M > kTileM && pad256 * 100 <= pad128 * 115 &&
           st.rhs >= 0 && P.tensors[st.lhs].numel <= (1LL << 30) && P.tensors[st.rhs].numel <= (1LL << 30)) {  // 32-bit byte offsets
