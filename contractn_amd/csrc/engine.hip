@@ -449,7 +449,7 @@ static int exec_launch_steps(Exec* E) {
     a.obA2 = T + st.t.obA2; a.omA2 = T + st.t.omA2; a.okA2 = T + st.t.okA2;
     a.idA2 = st.lhs2 >= 0 ? st.lhs2 : E->n_tensors - 1;
     a.krX = st.krX; a.krY = st.krY;
-    a.epw = st.epw;
+    a.epw = st.epw | (st.epw_split ? 0x100 : 0);
     double* part_dst = E->d_partials + (size_t)E->step_off[s] * R;
     const int part_stride = E->step_partials[s];    // slots per replica of this step's region
     a.partC = st.collapse ? E->d_scratch : part_dst;

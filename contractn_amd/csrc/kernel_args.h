@@ -69,7 +69,7 @@ struct StepArgs {
   int32_t krX, krY;   // modes 4 / 5: how each factor is read along the vector direction (0 gather, 1 float4, 2 broadcast)
   // epilogue-summed GEMM (planner pattern C): extent (2 / 4) of the innermost column label that tensor idA2 -
   // offsets of the rows in omA2, the label itself unit-stride - re-weights and sums on the way out; 0 = plain step
-  int32_t epw;
+  int32_t epw;        // | 0x100: columns ordered (.., u_hi, p, u_lo), see Step::epw_split
 };
 
 struct FinalArgs {

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
       const float iW = 1.0f / scW;
       const float w0 = wp[0], w1 = wp[1];
       float w2 = 0.f, w3 = 0.f;
-      if (a.epw == 4) { w2 = wp[2]; w3 = wp[3]; }
+      if ((a.epw & 0xFF) == 4) { w2 = wp[2]; w3 = wp[3]; }
       *reinterpret_cast<float4*>(s_W + 4 * tid) = make_float4(w0 * iW, w1 * iW, w2 * iW, w3 * iW);
     }
     __syncthreads();
@@ -533,10 +533,31 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
         const int row = wm + i * 32 + lrow;
         const float4 v = *reinterpret_cast<const float4*>(wC + lrow * WT + c4);
         if constexpr (EPW) {
-          if (m0 + row < a.M && cin) {
+          const int P = a.epw & 0xFF;
+          if (a.epw & 0x100) {
+            // columns ordered (.., u_hi, p, u_lo): this lane holds four consecutive u of ONE p, the other p of the
+            // same u sit in the adjacent lanes - weight, then add across the 2 / 4 lanes; the p = 0 lane stores
+            const bool in = m0 + row < a.M && cin;
+            const int pidx = (gcol >> 2) & (P - 1);
+            const float wq = in ? s_W[4 * row + pidx] : 0.f;
+            float4 x = make_float4(v.x * wq, v.y * wq, v.z * wq, v.w * wq);
+            x.x += __shfl_xor(x.x, 1, 64); x.y += __shfl_xor(x.y, 1, 64); x.z += __shfl_xor(x.z, 1, 64); x.w += __shfl_xor(x.w, 1, 64);
+            if (P == 4) {
+              x.x += __shfl_xor(x.x, 2, 64); x.y += __shfl_xor(x.y, 2, 64); x.z += __shfl_xor(x.z, 2, 64); x.w += __shfl_xor(x.w, 2, 64);
+            }
+            if (in && pidx == 0) {
+              float* dst = C + s_omC[row];
+              if (a.c_vec) {
+                *reinterpret_cast<float4*>(dst + offn) = x;
+              } else {
+                dst[offn] = x.x; dst[s_onC[gcol + 1]] = x.y; dst[s_onC[gcol + 2]] = x.z; dst[s_onC[gcol + 3]] = x.w;
+              }
+              asum += (fabsf(x.x) + fabsf(x.y)) + (fabsf(x.z) + fabsf(x.w));
+            }
+          } else if (m0 + row < a.M && cin) {
             float* dst = C + s_omC[row];
             const float4 wv = *reinterpret_cast<const float4*>(s_W + 4 * row);
-            if (a.epw == 4) {
+            if (P == 4) {
               const float o = (v.x * wv.x + v.y * wv.y) + (v.z * wv.z + v.w * wv.w);
               dst[offn] = o;
               asum += fabsf(o);

@@ -462,6 +462,26 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     for (size_t a = 0; a < out.labels.size(); ++a) { out.numel *= out.dims[a]; find(out.labels[a])->sC = out.strides[a]; }
     if (out.numel >= (1LL << 31)) { err = "tensors with >= 2^31 elements are not supported"; return CTN_UNSUPPORTED; }
 
+    // Epilogue-summed steps: with the summed label p innermost, four adjacent columns are the four p of ONE r - the B
+    // operand is then gathered four bytes at a time and so is the output.  When the next column label u is unit-stride
+    // in B (r of an MPS core), split it as u = 4 u_hi + u_lo and order the columns (..., u_hi, p, u_lo): a lane's
+    // four columns are four consecutive u of one p (16-byte loads of B, 16-byte stores of C), and the sum over p
+    // runs across 2 / 4 adjacent lanes.  Synthetic labels live in `synth`; `split_parent` is the label they replace.
+    LabelInfo synth[2];
+    const LabelInfo* split_parent = nullptr;
+    if (epw && G[kN].size() >= 2) {
+      LabelInfo* u = G[kN][G[kN].size() - 2];
+      if (u->inB && u->sB == 1 && u->ext % vec == 0 && vec == 4) {
+        synth[0] = *u; synth[0].ext = u->ext / 4; synth[0].sB = 4 * u->sB; synth[0].sC = 4 * u->sC;
+        synth[1] = *u; synth[1].ext = 4;
+        LabelInfo* pl = G[kN].back();
+        G[kN].pop_back(); G[kN].pop_back();
+        G[kN].push_back(&synth[0]); G[kN].push_back(pl); G[kN].push_back(&synth[1]);
+        split_parent = u;
+        st.epw_split = true;
+      }
+    }
+
     auto extent = [](const std::vector<LabelInfo*>& g) { int64_t n = 1; for (auto* l : g) n *= l->ext; return n; };
     st.Bt = extent(G[kBatch]); st.M = extent(G[kM]); st.N = extent(G[kN]); st.K = extent(G[kK]);
     st.has_k = !G[kK].empty();
@@ -475,7 +495,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       auto present = [&](const LabelInfo* l) { return isA ? l->inA : l->inB; };
       const auto& freeG = isA ? G[kM] : G[kN];
       auto others_ok = [&](const LabelInfo* unit) {
-        for (auto& l : info) if (&l != unit && present(&l) && stride(&l) % vec != 0) return false;
+        for (auto& l : info) if (&l != unit && &l != split_parent && present(&l) && stride(&l) % vec != 0) return false;
         return true;
       };
       if (!freeG.empty()) {
@@ -512,7 +532,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     if (!G[kN].empty()) {
       const LabelInfo* u = G[kN].back();
       bool ok = u->sC == 1 && u->ext % vec == 0;
-      for (auto& l : info) if (&l != u && l.inC && l.sC % vec != 0) ok = false;
+      for (auto& l : info) if (&l != u && &l != split_parent && l.inC && l.sC % vec != 0) ok = false;
       st.cvec = ok;
     }
 

@@ -55,6 +55,8 @@ struct Step {
   int krX = 0, krY = 0;  // modeA 4 / 5: how each factor is read along the vector direction (0 gather, 1 float4, 2 broadcast)
   int epw = 0;           // 2 / 4: the step is a GEMM whose innermost column label (this extent) is re-weighted by
                          // tensors[lhs2] and summed in the epilogue ("bl,plr->bpr" then "bpr,bp->br" as one step)
+  bool epw_split = false;  // ... with the columns ordered (.., u_hi, p, u_lo), |u_lo| = 4: a lane's four columns are four
+                           // consecutive u of one p (vector accesses); the sum over p runs across adjacent lanes
   bool swapped = false;
   int kernel = CTN_KERNEL_ELEMENT;
   int64_t Bt = 1, M = 1, N = 1, K = 1;
