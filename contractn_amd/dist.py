@@ -1,11 +1,14 @@
 """Multi-GPU execution of the contraction path: one process per GPU, RCCL over xGMI.
 
 The reference has no distributed layer at all.  The path
-shards in three ways:
+shards in four ways:
 
 * **replicas** - independent networks (same plan, different tensors) are dealt
   round-robin to the ranks; there is NO data-path collective
   (:func:`shard_range`; this is what ``bench.py --gpus N`` does);
+* **batch sharding** - one network with a batch hyperedge (an OUTPUT label every input hangs on: the paper's
+  ML workload): every rank takes a chunk of the label's range, no collective on the data path, ONE
+  ``all_gather`` of the chunks' results concatenates them (:func:`contract_batch_sharded`);
 * **independent subtrees** - one network whose contraction tree is cut near the root: the subtrees are
   dealt to the ranks, their (small) results are exchanged by ONE ``all_gather`` and every rank finishes
   the top of the tree (:func:`contract_subtrees`; for networks with small cuts, e.g. PEPS with D <= 3);
@@ -309,6 +312,95 @@ def all_gather_combine(t_loc, c_loc, group=None, world=None, device=None):
         arr = buf.cpu().numpy()
         parts.append((arr[:-1].reshape(np.shape(t_loc)).astype(np.asarray(t_loc).dtype), arr[-1]))
     return combine_split(parts)
+
+
+# ---------------------------------------------------------------------------
+# batch sharding ("batched workloads ... are embarrassingly data-parallel: replicas only,
+# concatenate outputs")
+# ---------------------------------------------------------------------------
+def concat_split(parts, axis):
+    """Concatenate tensors given in split format ``[(T_hat, c), ...]`` along ``axis`` without leaving it:
+    ``T = concat_g T_hat_g exp(c_g - c*)`` with ``c* = max c_g`` over the non-zero pieces, re-stabilised like a
+    contraction step (mean |T_hat| == 1; reference einsum.py:89-107)."""
+    parts = [(np.asarray(t), float(c)) for t, c in parts]
+    live = [c for t, c in parts if np.any(t != 0)]
+    dtype = parts[0][0].dtype
+    if not live:
+        return np.concatenate([t for t, _ in parts], axis=axis), np.zeros(())
+    c_star = max(live)
+    total = np.concatenate([t.astype(np.float64) * (np.exp(c - c_star) if np.any(t != 0) else 0.0) for t, c in parts], axis=axis)
+    norm = np.sum(np.abs(total))
+    if norm > 1e-7:
+        rescale = norm / total.size
+        total = total / rescale
+        c_star = c_star + np.log(rescale)
+    return total.astype(dtype), np.asarray(c_star, dtype=np.float64)
+
+
+def shard_batch_label(einstr, operands, label, rank, world):
+    """This rank's share of a data-parallel contraction over the OUTPUT label ``label`` (a batch hyperedge: the
+    copy node every input hangs on): its contiguous chunk ``[lo, hi)`` of the label's range, with every operand that
+    carries the label cut down to it (views, no copies) and the others passed through.  Returns
+    ``(operands, lo, hi, out_axis)``; the einsum string is unchanged."""
+    lhs, out = einstr.split("->")
+    terms = lhs.split(",")
+    if label not in out:
+        raise ValueError(f"'{label}' is summed: shard it with SlicedContraction, not as a batch")
+    shapes = [tuple(o.shape) for o in operands]
+    _, _, sizes = paths.parse_einsum_input(einstr, shapes)
+    mine_r = shard_range(sizes[label], rank, world)
+    lo, hi = mine_r.start, mine_r.stop
+    if hi <= lo:
+        raise ValueError(f"rank {rank} of {world} gets no part of label '{label}' (extent {sizes[label]})")
+    mine = []
+    for t, op in zip(terms, operands):
+        idx = tuple(slice(lo, hi) if s == label else slice(None) for s in t)
+        mine.append(op[idx] if label in t else op)
+    return mine, lo, hi, out.index(label)
+
+
+def contract_batch_sharded(einstr, operands, label, optimize="auto", contract_fn=None, group=None, rank=None,
+                           world=None, device=None):
+    """Data-parallel contraction over a batch label: rank g contracts chunk g of the label's range on its own
+    GPU - no collective on the data path - and ONE all_gather of the chunks' split-format results ``(T_hat_g, c_g)``
+    joins them into the full ``(T_hat, c)`` on every rank (`concat_split`).  ``contract_fn(einstr, *ops,
+    optimize=..., split_format=True)`` defaults to the HIP engine.  NumPy operands and results (a classifier's
+    outputs are B numbers); the chunks' operands may be any strided views."""
+    import torch
+    import torch.distributed as dist
+
+    if contract_fn is None:
+        from .einsum import contract as contract_fn
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = (dist.get_rank(group) if distributed else 0) if rank is None else rank
+    world = (dist.get_world_size(group) if distributed else 1) if world is None else world
+    mine, lo, hi, axis = shard_batch_label(einstr, operands, label, rank, world)
+    mine = [np.ascontiguousarray(o) for o in mine]
+    t_loc, c_loc = contract_fn(einstr, *mine, optimize=optimize, split_format=True)
+    t_loc = np.asarray(t_loc)
+    if world == 1 or not distributed:
+        return t_loc, np.asarray(float(c_loc), dtype=np.float64)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device) if backend == "nccl" else torch.device("cpu")
+    shapes = [tuple(o.shape) for o in operands]
+    _, _, sizes = paths.parse_einsum_input(einstr, shapes)
+    # chunks may differ by one index: pad every rank's buffer to the largest chunk
+    per = t_loc.size // (hi - lo)
+    widest = max(len(shard_range(sizes[label], g, world)) for g in range(world))
+    flat = np.zeros(widest * per + 1, dtype=np.float64)
+    flat[:t_loc.size] = np.moveaxis(t_loc, axis, 0).astype(np.float64).ravel()
+    flat[-1] = float(c_loc)
+    send = torch.from_numpy(flat).to(dev)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    parts = []
+    rest = tuple(np.delete(np.array(t_loc.shape), axis))
+    for g, buf in enumerate(recv):
+        arr = buf.cpu().numpy()
+        n_g = len(shard_range(sizes[label], g, world))
+        piece = arr[:n_g * per].reshape((n_g,) + tuple(int(x) for x in rest))
+        parts.append((np.moveaxis(piece, 0, axis).astype(t_loc.dtype), arr[-1]))
+    return concat_split(parts, axis)
 
 
 # ---------------------------------------------------------------------------

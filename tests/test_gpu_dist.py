@@ -220,3 +220,67 @@ def test_open_output_device_join_one_and_two_ranks():
         assert np.max(np.abs(got - ref)) <= 1e-4 * np.max(np.abs(ref))
         assert abs(np.mean(np.abs(t)) - 1.0) < 1e-4
     assert np.array_equal(results[0][1], results[1][1]) and results[0][2] == results[1][2]
+
+
+def _batch_rank_main(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as tdist
+
+    from contractn_amd import dist
+
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        einstr, ops, path, label = _batched_network()
+        t, c = dist.contract_batch_sharded(einstr, ops, label, optimize=path, device=0)   # HIP engine on this rank's chunk
+        q.put((rank, np.asarray(t), float(c)))
+    finally:
+        tdist.destroy_process_group()
+
+
+def _batched_network():
+    """BASELINE config 3b in small: 1000 inputs through a 6-site MPS (D = 64, d = 4) hanging on a batch hyperedge."""
+    from contractn_amd import TN
+    from contractn_amd import einsum as E
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+
+    tn, inputs = nets.batched_mps(TN, 6, 64, 4, 1000, dtype=np.float32, seed=4)
+    ops = [np.asarray(o) for o in E.make_arg_packer(tn)(tn.params, inputs)]
+    path = ssa_to_linear(nets.batched_mps_path(6), 12)
+    return tn.einsum_str, ops, path, tn.einsum_str.split("->")[1]
+
+
+def test_two_ranks_batch_sharded_classifier_outputs():
+    """The data-parallel mode of SURVEY.md 8(e) for batched workloads: each rank evaluates its 500 inputs on the
+    engine (one launch per interior site, the physical leg summed in the GEMM's epilogue), ONE all_gather
+    concatenates the split-format chunks - equal to the unsharded engine result and to the oracle."""
+    import torch.multiprocessing as mp
+
+    from contractn_amd import contract
+    from oracle import cpu_ref
+
+    einstr, ops, path, label = _batched_network()
+    t_u, c_u = contract(einstr, *ops, optimize=path, split_format=True)
+    rt, rc = cpu_ref.contract(einstr, *ops, path=list(path), split_format=True)
+    ref = np.asarray(rt, dtype=np.float64) * np.exp(float(rc))
+    one = t_u.astype(np.float64) * np.exp(float(c_u))
+    assert np.max(np.abs(one - ref)) <= 1e-3 * np.max(np.abs(ref))
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_batch_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(((r, t, c) for r, t, c in (q.get(timeout=300) for _ in procs)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for _r, t, c in results:
+        got = t.astype(np.float64) * np.exp(c)
+        assert t.shape == (1000,) and t.dtype == np.float32
+        assert np.max(np.abs(got - ref)) <= 1e-3 * np.max(np.abs(ref))
+        assert np.max(np.abs(got - one)) <= 1e-5 * np.max(np.abs(one))
+        assert abs(np.mean(np.abs(t)) - 1.0) < 1e-5
+    assert np.array_equal(results[0][1], results[1][1]) and results[0][2] == results[1][2]
