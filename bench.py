@@ -49,6 +49,9 @@ def parse_args():
                     help="mps: skip the secondary PEPS strong-scaling measurement that follows the headline")
     ap.add_argument("--peps-bonds", type=int, nargs="*", default=[8, 16], help="mps: bond dimensions of that secondary")
     ap.add_argument("--peps-timeout", type=float, default=240.0, help="mps: watchdog for the secondary, seconds")
+    ap.add_argument("--no-batched", dest="with_batched", action="store_false",
+                    help="mps: skip the secondary batched-MPS (BASELINE config 3b) measurement")
+    ap.add_argument("--batch", type=int, default=4096, help="mps: inputs per GPU of that secondary")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -125,12 +128,98 @@ def main():
         result = run_peps(args, world, rank, local_rank, backend, dev)
     else:
         result = run_mps(args, world, rank, local_rank, backend, dev)
+        if args.with_batched and args.dtype == "f32":
+            batched_secondary(args, result, world, rank, backend, dev)
         if args.with_peps and args.dtype == "f32":
             peps_secondary(args, result, world, rank, local_rank, backend, dev)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def batched_secondary(args, result, world, rank, backend, dev):
+    """BASELINE config 3b next to the headline: `--batch` inputs per GPU through ONE 100-site MPS (D = 256, d = 4)
+    hanging on a batch hyperedge - the reference paper's ML workload (README Fig. 1d).  Data-parallel over the
+    batch (weak scaling, no collective on the data path: SURVEY.md 8e); value = inputs/s over all ranks.  On one
+    GPU the first 64 outputs are checked against the oracle run on those 64 inputs alone (batch independence).
+    Errors are recorded in the object; the headline line is printed regardless."""
+    import torch
+    import torch.distributed as dist
+
+    out = result.setdefault("batched_mps", {}) if rank == 0 else {}
+    try:
+        from contractn_amd import TN
+        from contractn_amd.einsum import BatchedContraction, accumulate_log_scale
+        from contractn_amd.paths import ssa_to_linear
+        from tests import networks as nets
+
+        B, n_sites, bond, phys = args.batch, args.sites, args.bond, args.phys
+
+        class Shape:
+            def __init__(self, shape):
+                self.shape, self.ndim = tuple(shape), len(shape)
+
+        tn = TN()
+        hub = tn.add_copy_node(n_sites + 1)
+        cores = [Shape((phys, bond) if i in (0, n_sites - 1) else (phys, bond, bond)) for i in range(n_sites)]
+        nodes = nets.add_mps(tn, cores)
+        for i, node in enumerate(nodes):
+            inp = tn.add_input_node((B, phys), var_shape_axes=(0,))
+            tn.connect_nodes(inp, node, 1, 0)
+            tn.connect_nodes(hub, inp, i, 0)
+        shapes = [c.shape for c in cores] + [(B, phys)] * n_sites
+        path = ssa_to_linear(nets.batched_mps_path(n_sites), 2 * n_sites)
+        bc = BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=1, device=dev.index)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(11 + rank)
+        ops = [torch.randn(sh, generator=gen, device=dev) / 4.0 for sh in shapes]
+        res = torch.zeros((1,) + tuple(bc.plan.out_shape), device=dev)
+        launch = bc.executor.make_enqueue([t.data_ptr() for t in ops], [res[0].data_ptr()])
+        for _ in range(3):
+            launch()
+        bc.executor.synchronize()
+        K = max(args.steps, 10)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            launch()
+        bc.executor.synchronize()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        sec = float(dt.item()) / K
+        if rank != 0:
+            return
+        infos = bc.plan.step_infos()
+        launches = sum(i["kernel"] != 5 for i in infos)
+        out.update({
+            "workload": f"batched_mps_{n_sites}sites_D{bond}_d{phys}_B{B}_per_gpu", "value": round(world * B / sec, 1),
+            "unit": "inputs/s", "ms_per_pass": round(sec * 1e3, 4), "passes": K, "scaling": "weak",
+            "achieved_tflops": round(world * bc.plan.flops / sec / 1e12, 2),
+            "frac_of_mfma_peak": round(bc.plan.flops / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "launches_per_pass": launches, "epilogue_summed_steps": sum(i["epilogue_sum"] > 0 for i in infos),
+            "largest_intermediate_elements": max(i["out_numel"] for i in infos if i["kernel"] != 5),
+        })
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import cpu_ref
+
+            _dev_log, resc = bc.executor.fetch()
+            c = float(accumulate_log_scale(resc[0], np.dtype(np.float32)))
+            got = res[0, :64].cpu().numpy().astype(np.float64) * np.exp(c)
+            h_ops = [o[:64].cpu().numpy() if tuple(o.shape) == (B, phys) else o.cpu().numpy() for o in ops]
+            rt, rc = cpu_ref.contract(tn.einsum_str, *h_ops, path=list(path), split_format=True)
+            ref = np.asarray(rt, dtype=np.float64) * np.exp(float(rc))
+            err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+            out["parity_vs_oracle_first_64_inputs"] = {"ok": bool(err <= 1e-3), "max_rel_err": err, "tolerance": 1e-3}
+    except Exception as exc:  # noqa: BLE001 - recorded, the headline line must still be printed
+        if rank == 0:
+            out["error"] = repr(exc)
+    finally:
+        torch.cuda.empty_cache()
 
 
 def peps_secondary(args, result, world, rank, local_rank, backend, dev):
