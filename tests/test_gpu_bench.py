@@ -36,3 +36,9 @@ def test_bench_line_contract(dtype):
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
     assert cpu["parity_vs_gpu"]["ok"] is True          # replica 0 of this very run against the oracle
     assert r["device"]["compute_units"] > 0
+    if dtype == "f32":   # the secondaries ride on the fp32 line and never replace it
+        b = r["batched_mps"]
+        assert "error" not in b, b
+        assert b["unit"] == "inputs/s" and b["value"] > 0 and b["scaling"] == "weak"
+        assert b["epilogue_summed_steps"] == 12 - 2 and b["parity_vs_oracle_first_64_inputs"]["ok"] is True
+        assert "peps_strong_scaling" in r
