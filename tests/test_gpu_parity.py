@@ -795,6 +795,7 @@ def test_fused_gemm_with_reweighting_consumer_batched_mps(force_fusion_kr):
     ("bl,plr,bp->rb", [(256, 64), (4, 64, 64), (256, 4)]),          # last step, caller's axis order
     ("abl,plr,abp->abr", [(16, 32, 48), (2, 48, 64), (16, 32, 2)]), # two row labels in the weights
     ("bl,plr,bp->br", [(192, 64), (4, 64, 96), (192, 4)]),          # 64-row tiles (M = 192)
+    ("abl,plr,bp->abr", [(16, 32, 48), (4, 48, 32), (32, 4)]),     # a row label the weights do not carry
 ])
 def test_epilogue_sum_step_vs_numpy(einstr, shapes):
     rng = np.random.default_rng(23)
