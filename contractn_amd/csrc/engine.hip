@@ -46,6 +46,7 @@ struct DevSwitches {
   int mfma_g = 1;        // CTN_MFMA_G: 0 never use the large-tile LDS-DMA kernels, 1 when a launch fills the chip, 2 whenever eligible (tests)
   int graph = 1;         // CTN_GRAPH=0: every enqueue issues its launches one by one
   int mfma_bk = 0;       // CTN_MFMA_BK=16|32: force the k-tile depth of k_mfma_f32
+  int group = 1;         // CTN_GROUP=0: never batch independent leaf steps into one launch (k_stream_group)
   int halve = 1;         // CTN_HALVE_TILES=0: never halve the tiles of an under-filled register-staged launch
   int lat64_min_k = 512; // CTN_LAT64_MIN_K: least K for the 64 x 64 one-launch latency form when an operand is k-contiguous
   int splitk = -1;       // CTN_SPLITK: 0 disables the latency mode, 1 forces it for every eligible step (tests)
@@ -67,6 +68,7 @@ static DevSwitches read_dev_switches() {
   d.lat = num("CTN_LAT", -1);
   d.lat64_min_k = num("CTN_LAT64_MIN_K", 512);
   d.halve = num("CTN_HALVE_TILES", 1);
+  d.group = num("CTN_GROUP", 1);
   d.g_no_asm = getenv("CTN_G_NO_ASM") != nullptr;
   d.stamps = getenv("CTN_DEBUG_STAMPS");
   d.stamp_step = num("CTN_DEBUG_STAMP_STEP", -1);
@@ -149,6 +151,13 @@ struct Exec {
   bool eager_forced = false;        // ctn_exec_set_rescale_mode(1)
   int eager_reruns = 0;
   std::vector<double> h_resc;       // host copy of the last run's per-step rescale factors [R][n_steps]
+  // Grouped leaf steps: runs of consecutive streaming steps whose operands are all network inputs (independent of
+  // each other and of everything before them) go out as ONE launch of k_stream_group; their arguments never
+  // change, so they are built on the first enqueue and kept in device memory.
+  struct LeafGroup { int len = 0, vw = 1, u = 1, blocks = 1, off = 0; bool ready = false; };
+  std::vector<LeafGroup> groups;    // per step: len >= 2 at the head of a group, else 0
+  std::vector<StepArgs> h_group_args;
+  StepArgs* d_group_args = nullptr;
   int timing_slots = 0;             // 0 = timing off
   int timing_runs = 0;              // enqueues recorded since timing was enabled
   std::vector<hipEvent_t> events;   // [slot][step][2]
@@ -158,7 +167,7 @@ struct Exec {
     for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch, (void*)d_slab, (void*)d_slab2,
                     (void*)d_log, (void*)d_resc, (void*)d_logs, (void*)d_chain, d_ones, (void*)d_stepP, (void*)d_stepNumel,
                     (void*)d_stepOff, (void*)d_stepSlots,
-                    (void*)d_stage_in, (void*)d_stage_out})
+                    (void*)d_stage_in, (void*)d_stage_out, (void*)d_group_args})
       if (p) (void)hipFree(p);
     if (h_pack) (void)hipHostFree(h_pack);
     for (auto ev : events) (void)hipEventDestroy(ev);
@@ -334,6 +343,26 @@ static int stream_splits(const Step& st, int R, int n_cu) {
   return (int)std::max<int64_t>(2, std::min<int64_t>(std::min<int64_t>(st.K / 128, 1024), (8LL * n_cu + wgs - 1) / wgs));
 }
 
+// k_stream variant of a plain streaming step: vector width along n and vectors per row lookup (4 only where it pays:
+// short K - lookup-dominated - and enough rows left to fill the chip; long-K / small steps keep one for parallelism)
+static void stream_variant(const Step& st, int R, int vw, int* u, int64_t* nq) {
+  *nq = (st.Nv + vw - 1) / vw;
+  const int64_t rows = st.H * st.L * (int64_t)R;
+  *u = (*nq % 4 == 0 && st.K <= 16 && rows * (*nq / 4) >= (1 << 20)) ? 4 : 1;
+}
+
+template <typename T>
+static void launch_stream_group(int vw, int u, dim3 g, hipStream_t st, const StepArgs* arr) {
+  constexpr int VF = 16 / (int)sizeof(T);
+  if (vw == VF) {
+    if (u == 4) hipLaunchKernelGGL((k_stream_group<T, VF, 4>), g, dim3(256), 0, st, arr);
+    else hipLaunchKernelGGL((k_stream_group<T, VF, 1>), g, dim3(256), 0, st, arr);
+  } else {
+    if (u == 4) hipLaunchKernelGGL((k_stream_group<T, 1, 4>), g, dim3(256), 0, st, arr);
+    else hipLaunchKernelGGL((k_stream_group<T, 1, 1>), g, dim3(256), 0, st, arr);
+  }
+}
+
 // Row-dot steps (one wave per output) with few outputs and a long K: split K over workgroups too
 static int rowdot_splits(const Step& st, int R, int n_cu) {
   if (st.kernel != CTN_KERNEL_ROWDOT || st.K < 4096) return 0;
@@ -417,8 +446,22 @@ static int exec_launch_steps(Exec* E) {
                          (void* const*)E->d_ptrs, E->n_tensors, E->d_partials, R, P.min_norm, P.stabilize ? 1 : 0);
     if (timed) HIPCHECK(hipEventRecord(E->events[ev0 + 1], E->stream));  // whole walk = "step 0"
   }
+  int group_skip = 0, collect_left = 0, collect_head = -1;
   for (int s = 0; s < P.n_steps && !chain; ++s) {
     const Step& st = P.steps[s];
+    if (group_skip > 0) { --group_skip; continue; }   // went out with the head of its group
+    if (collect_left == 0 && !E->groups.empty() && E->groups[s].len >= 2 && E->sw.group && !E->eager_rescale &&
+        !(E->timing_runs < E->timing_slots)) {
+      Exec::LeafGroup& G = E->groups[s];
+      if (G.ready) {
+        const dim3 g(G.blocks, R, G.len);
+        if (P.dtype == CTN_F32) launch_stream_group<float>(G.vw, G.u, g, E->stream, E->d_group_args + G.off);
+        else launch_stream_group<double>(G.vw, G.u, g, E->stream, E->d_group_args + G.off);
+        group_skip = G.len - 1;
+        continue;
+      }
+      collect_left = G.len; collect_head = s;   // first time: the steps' arguments are built below, not launched
+    }
     if (st.kernel == CTN_KERNEL_FUSED) {   // formed on the fly inside its consumer: nothing to launch
       if (E->timing_runs < E->timing_slots) {
         const size_t e0 = ((size_t)E->timing_runs * P.n_steps + s) * 2;
@@ -697,12 +740,23 @@ static int exec_launch_steps(Exec* E) {
         }
         // vector stores need a 16-byte aligned destination: the caller's final buffer may not be
         const int vw = (s + 1 == P.n_steps && !E->outs_aligned16) ? 1 : st.vecw;
-        const int64_t nq = (st.Nv + vw - 1) / vw;
-        // 4 vectors per row lookup only where it pays: short K (lookup-dominated) and enough rows
-        // left to fill the chip; long-K / small steps keep one vector per thread for parallelism
-        const int64_t rows = st.H * st.L * (int64_t)R;
-        const int u = (nq % 4 == 0 && st.K <= 16 && rows * (nq / 4) >= (1 << 20)) ? 4 : 1;
+        int u;
+        int64_t nq;
+        stream_variant(st, R, vw, &u, &nq);
         a.dNq = make_fastdiv(nq / u);
+        if (collect_left > 0) {   // a grouped leaf step: keep the arguments; the last one uploads and launches the group
+          Exec::LeafGroup& G = E->groups[collect_head];
+          E->h_group_args[G.off + (s - collect_head)] = a;
+          if (--collect_left == 0) {
+            HIPCHECK(hipMemcpyAsync(E->d_group_args + G.off, E->h_group_args.data() + G.off, sizeof(StepArgs) * G.len,
+                                    hipMemcpyHostToDevice, E->stream));
+            G.ready = true;
+            const dim3 gg(G.blocks, R, G.len);
+            if (P.dtype == CTN_F32) launch_stream_group<float>(G.vw, G.u, gg, E->stream, E->d_group_args + G.off);
+            else launch_stream_group<double>(G.vw, G.u, gg, E->stream, E->d_group_args + G.off);
+          }
+          break;
+        }
         const int ks = E->d_slab ? stream_splits(st, R, E->n_cu) : 0;
         SplitKArgs sk{};
         if (ks) {
@@ -1023,6 +1077,39 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     }
     E.step_off[s] = E.part_slots;
     E.part_slots += E.step_partials[s];
+  }
+  // leaf groups: runs of consecutive plain streaming steps on network inputs, same kernel variant (see Exec::LeafGroup)
+  if (!P.chain && E.sw.group) {
+    E.groups.assign(P.n_steps, Exec::LeafGroup());
+    auto leaf = [&](int s, int* vw, int* u) {
+      const Step& st = P.steps[s];
+      if (st.kernel != CTN_KERNEL_ELEMENT || st.kvec || st.collapse || s + 1 >= P.n_steps || st.rhs < 0 ||
+          st.lhs >= P.n_inputs || st.rhs >= P.n_inputs || st.lhs2 >= 0 || stream_splits(st, replicas, E.n_cu))
+        return false;
+      int64_t nq;
+      *vw = st.vecw;
+      stream_variant(st, replicas, *vw, u, &nq);
+      return true;
+    };
+    int total = 0;
+    for (int s = 0; s < P.n_steps;) {
+      int vw, u;
+      if (!leaf(s, &vw, &u)) { ++s; continue; }
+      int e = s + 1, blocks = P.steps[s].blocks, vw2, u2;
+      while (e < P.n_steps && e - s < 1024 && leaf(e, &vw2, &u2) && vw2 == vw && u2 == u) { blocks = std::max(blocks, P.steps[e].blocks); ++e; }
+      if (e - s >= 2) {
+        Exec::LeafGroup& G = E.groups[s];
+        G.len = e - s; G.vw = vw; G.u = u; G.blocks = blocks; G.off = total;
+        total += G.len;
+      }
+      s = e;
+    }
+    if (total) {
+      E.h_group_args.resize(total);
+      HIPCHECK_X(hipMalloc((void**)&E.d_group_args, sizeof(StepArgs) * (size_t)total));
+    } else {
+      E.groups.clear();
+    }
   }
   HIPCHECK_X(hipMalloc((void**)&E.d_scratch, (size_t)replicas * scratch_need * 8));
   HIPCHECK_X(hipMalloc((void**)&E.d_partials, (size_t)E.part_slots * replicas * 8));

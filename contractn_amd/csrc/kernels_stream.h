@@ -48,7 +48,8 @@ __device__ __forceinline__ void load_vec(const T* __restrict__ p, int stride_n, 
 // 2U loads of an item are issued back to back before any arithmetic.
 template <typename T, int V, int U, bool DA, bool DB>
 __device__ __forceinline__ double stream_items(const StepArgs& a, const T* __restrict__ A, const T* __restrict__ B,
-                                               T* __restrict__ C, T sA, T sB, int kbeg = 0, int kend = -1) {
+                                               T* __restrict__ C, T sA, T sB, int kbeg = 0, int kend = -1,
+                                               uint32_t nblocks = 0) {
   const uint32_t nq_per = (uint32_t)((a.Nv + V - 1) / V);
   const uint32_t S = nq_per / U;                 // U divides nq_per (checked on the host)
   const uint32_t items = (uint32_t)a.H * (uint32_t)a.L * S;  // < 2^31
@@ -56,7 +57,7 @@ __device__ __forceinline__ double stream_items(const StepArgs& a, const T* __res
   const bool kone = a.K == 1;                    // pure product: k-offset tables hold a single 0
   const int stepA = (int)S * V * a.sAn, stepB = (int)S * V * a.sBn;
   double absv = 0;
-  const uint32_t stride = gridDim.x * 256u;
+  const uint32_t stride = (nblocks ? nblocks : gridDim.x) * 256u;   // (a grouped launch is as wide as its widest step)
   for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += stride) {
     const uint32_t row = dq.div(it);
     const int c0 = (int)(it - row * S) * V;
@@ -135,6 +136,32 @@ __global__ __launch_bounds__(256) void k_stream(StepArgs a) {
   else if (da && !db) absv = stream_items<T, V, U, true, false>(a, A, B, C, sA, sB);
   else if (!da && db) absv = stream_items<T, V, U, false, true>(a, A, B, C, sA, sB);
   else absv = stream_items<T, V, U, true, true>(a, A, B, C, sA, sB);
+  const double tot = block_sum(absv, red);
+  if (threadIdx.x == 0) a.partC[(size_t)r * a.partC_stride + blockIdx.x] = tot;
+}
+
+// Several INDEPENDENT streaming steps in one launch (blockIdx.z = the step; their arguments in device memory): the
+// physical-leg absorptions at the leaves of a PEPS / MPS contraction tree are dozens of few-kilobyte products whose
+// launches (5.5 us each in the trace) outweigh their work.  Same arithmetic as k_stream step by step.
+template <typename T, int V, int U>
+__global__ __launch_bounds__(256) void k_stream_group(const StepArgs* __restrict__ steps) {
+  __shared__ double red[4];
+  const StepArgs& a = steps[blockIdx.z];
+  if ((int)blockIdx.x >= a.blocks_per_replica) return;   // uniform per workgroup: narrower than the widest step
+  const int r = blockIdx.y;
+  const T sA = producer_scale<T>(a.partA, a.PA, a.strideA, a.numelA, a.min_norm, r);
+  const T sB = producer_scale<T>(a.partB, a.PB, a.strideB, a.numelB, a.min_norm, r);
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const T* __restrict__ A = (const T*)tp[a.idA];
+  const T* __restrict__ B = (const T*)tp[a.idB];
+  T* __restrict__ C = (T*)tp[a.idC];
+  const bool da = sA != (T)1, db = sB != (T)1;
+  const uint32_t nb = (uint32_t)a.blocks_per_replica;
+  double absv;
+  if (!da && !db) absv = stream_items<T, V, U, false, false>(a, A, B, C, sA, sB, 0, -1, nb);
+  else if (da && !db) absv = stream_items<T, V, U, true, false>(a, A, B, C, sA, sB, 0, -1, nb);
+  else if (!da && db) absv = stream_items<T, V, U, false, true>(a, A, B, C, sA, sB, 0, -1, nb);
+  else absv = stream_items<T, V, U, true, true>(a, A, B, C, sA, sB, 0, -1, nb);
   const double tot = block_sum(absv, red);
   if (threadIdx.x == 0) a.partC[(size_t)r * a.partC_stride + blockIdx.x] = tot;
 }

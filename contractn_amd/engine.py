@@ -187,6 +187,45 @@ def _ptr(arr, ctype):
     return arr.ctypes.data_as(C.POINTER(ctype))
 
 
+HOIST_MAX_NUMEL = 1 << 16
+
+
+def hoist_leaf_steps(n_inputs, in_labels, in_dims, steps, max_numel=HOIST_MAX_NUMEL):
+    """Execution order of a path: small steps whose two operands are NETWORK INPUTS (physical legs absorbed into
+    their sites: the leaves of a PEPS / MPS contraction tree) move to the front, everything else keeps its order.
+    They are independent of each other and of all other steps, and consecutive the engine sends them out as ONE
+    launch (`k_stream_group`) instead of dozens of 5-us ones.  Returns ``(steps in execution order, order)`` with
+    ``order[new] = old``, or ``(steps, None)`` when nothing moves.  Reporting (step info, rescales - hence the order
+    in which the log-scale register is accumulated, which stays the path's - timings, tiles) keeps the caller's step
+    numbers; only the order of launches changes.  ``CTN_HOIST=0`` disables."""
+    if os.environ.get("CTN_HOIST", "1") == "0" or len(steps) < 3:
+        return steps, None
+    ext = {}
+    for lab, dims in zip(in_labels, in_dims):
+        for l, d in zip(lab, dims):
+            ext[l] = int(d)
+
+    def numel(labels):
+        n = 1
+        for l in labels:
+            n *= ext.get(l, 1)
+        return n
+
+    small_in = [numel(lab) <= max_numel for lab in in_labels]
+    leaf = [i for i, (l, r, out) in enumerate(steps[:-1])
+            if 0 <= l < n_inputs and 0 <= r < n_inputs and small_in[l] and small_in[r] and numel(out) <= max_numel]
+    if len(leaf) < 2 or leaf == list(range(len(leaf))):
+        return steps, None
+    taken = set(leaf)
+    order = leaf + [i for i in range(len(steps)) if i not in taken]
+    new_id = {n_inputs + old: n_inputs + new for new, old in enumerate(order)}
+
+    def remap(t):
+        return t if t < n_inputs else new_id[t]
+
+    return [(remap(steps[o][0]), remap(steps[o][1]) if steps[o][1] >= 0 else -1, steps[o][2]) for o in order], order
+
+
 class Plan:
     """Immutable native plan for one (einsum string, shapes, path, dtype)."""
 
@@ -201,6 +240,11 @@ class Plan:
             code = CTN_F64
         else:
             raise TypeError(f"HIP engine supports float32/float64, got {self.np_dtype}")
+        steps = [(int(s[0]), int(s[1]), tuple(s[2])) for s in steps]
+        steps, order = hoist_leaf_steps(len(in_labels), in_labels, in_dims, steps)
+        # native step index of the caller's step i, and back (identity unless leaf steps were hoisted)
+        self._native_of = None if order is None else np.argsort(np.asarray(order)).astype(np.int64)
+        self._caller_of = None if order is None else np.asarray(order, dtype=np.int64)
         ndim = _i32(len(lab) for lab in in_labels)
         dims = _i64(d for shp in in_dims for d in shp)
         labels = _i32(l for lab in in_labels for l in lab)
@@ -241,9 +285,19 @@ class Plan:
     def workspace_bytes(self, replicas=1):
         return int(self._lib.ctn_plan_workspace_bytes(self._h, replicas))
 
+    def native_step(self, step):
+        """Index inside the native plan (its execution order) of the caller's step ``step``."""
+        return int(step) if self._native_of is None else int(self._native_of[step])
+
+    def in_caller_order(self, per_native_step, axis=-1):
+        """Re-index an array the library filled per native step by the caller's step numbers."""
+        if self._native_of is None:
+            return per_native_step
+        return np.take(per_native_step, self._native_of, axis=axis)
+
     def step_info(self, step):
         info = StepInfo()
-        _check(self._lib.ctn_plan_step_info(self._h, step, C.byref(info)))
+        _check(self._lib.ctn_plan_step_info(self._h, self.native_step(step), C.byref(info)))
         return {name: getattr(info, name) for name, _ in StepInfo._fields_}
 
     def step_infos(self):
@@ -309,7 +363,7 @@ class Executor:
             optrs[r] = outs.ctypes.data + r * stride
         _check(self._lib.ctn_exec_run(self._h, ptrs, CTN_MEM_HOST, optrs, CTN_MEM_HOST,
                                       _ptr(self._log, C.c_double), _ptr(self._resc, C.c_double)))
-        return outs, self._log.copy(), self._resc.copy()
+        return outs, self._log.copy(), plan.in_caller_order(self._resc).copy()
 
     # -- device pointers --------------------------------------------------------
     def enqueue(self, in_ptrs, out_ptrs):
@@ -338,7 +392,7 @@ class Executor:
     def fetch(self):
         _check(self._lib.ctn_exec_fetch(self._h, _ptr(self._log, C.c_double),
                                         _ptr(self._resc, C.c_double)))
-        return self._log.copy(), self._resc.copy()
+        return self._log.copy(), self.plan.in_caller_order(self._resc).copy()
 
     def synchronize(self):
         _check(self._lib.ctn_exec_synchronize(self._h))
@@ -361,14 +415,14 @@ class Executor:
         out = []
         tm, tn = C.c_int32(0), C.c_int32(0)
         for s in range(self.plan.n_steps):
-            _check(self._lib.ctn_exec_step_tile(self._h, s, C.byref(tm), C.byref(tn)))
+            _check(self._lib.ctn_exec_step_tile(self._h, self.plan.native_step(s), C.byref(tm), C.byref(tn)))
             out.append((tm.value, tn.value))
         return out
 
     def step_ms(self):
         ms = np.zeros(self.plan.n_steps, dtype=np.float32)
         _check(self._lib.ctn_exec_step_ms(self._h, _ptr(ms, C.c_float)))
-        return ms
+        return self.plan.in_caller_order(ms)
 
     def close(self):
         lock = getattr(self, "lock", None)

@@ -871,3 +871,35 @@ def test_fusion_is_off_for_small_intermediates_and_switchable(monkeypatch):
     off = _fused_infos("ac,ad,ae->cde", [(1024, 1024), (1024, 1024), (1024, 512)], ((0, 1), (0, 1)))
     assert all(i["kernel"] != 5 for i in off)
     E.clear_caches()
+
+
+# ---- leaf steps hoisted and sent out as one launch ------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_grouped_leaf_steps_give_the_same_bits_as_one_launch_each(dtype, monkeypatch):
+    """A PEPS path that absorbs each physical vector right before its site joins the boundary: the engine moves the
+    absorptions (steps on two network inputs) to the front and launches them as ONE kernel.  Same arithmetic per
+    step and the register still accumulated in the caller's step order, so the result is bit-identical to the plain
+    order with one launch per step (CTN_HOIST=0 CTN_GROUP=0) - and equal to the oracle on the caller's path."""
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from oracle import cpu_ref
+    from tests import networks as nets
+    from tests.test_plan_host import _interleaved_peps_path
+
+    rows, cols, bond = 4, 5, 4
+    tn = nets.peps_closed(TN, rows, cols, bond, dtype=dtype, seed=6)
+    path = ssa_to_linear(_interleaved_peps_path(rows, cols), 2 * rows * cols)
+    results = {}
+    for mode, env in (("grouped", {"CTN_HOIST": "1", "CTN_GROUP": "1"}), ("plain", {"CTN_HOIST": "0", "CTN_GROUP": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        E.clear_caches()
+        fun = tn.make_contract_fun(optimize=path, split_format=True)
+        outs = [fun(tn.params, ()) for _ in range(4)]           # eager launches, then the captured graph
+        assert all(float(t) == float(outs[0][0]) and float(c) == float(outs[0][1]) for t, c in outs)
+        results[mode] = (float(outs[0][0]), float(outs[0][1]))
+    E.clear_caches()
+    assert results["grouped"] == results["plain"]
+    rt, rc = cpu_ref.contract(tn.einsum_str, *tn.params, path=path, split_format=True)
+    tol = 1e-4 if dtype == np.float32 else 1e-10
+    assert results["grouped"][0] == float(rt) and abs(results["grouped"][1] - float(rc)) <= tol * max(1.0, abs(float(rc)))
