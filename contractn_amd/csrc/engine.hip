@@ -156,7 +156,7 @@ struct Exec {
   // change, so they are built on the first enqueue and kept in device memory.
   struct LeafGroup { int len = 0, vw = 1, u = 1, blocks = 1, off = 0; bool ready = false; };
   std::vector<LeafGroup> groups;    // per step: len >= 2 at the head of a group, else 0
-  std::vector<StepArgs> h_group_args;
+  StepArgs* h_group_args = nullptr; // pinned: the one-time upload may fall inside a stream capture
   StepArgs* d_group_args = nullptr;
   int timing_slots = 0;             // 0 = timing off
   int timing_runs = 0;              // enqueues recorded since timing was enabled
@@ -170,6 +170,7 @@ struct Exec {
                     (void*)d_stage_in, (void*)d_stage_out, (void*)d_group_args})
       if (p) (void)hipFree(p);
     if (h_pack) (void)hipHostFree(h_pack);
+    if (h_group_args) (void)hipHostFree(h_group_args);
     for (auto ev : events) (void)hipEventDestroy(ev);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -748,7 +749,7 @@ static int exec_launch_steps(Exec* E) {
           Exec::LeafGroup& G = E->groups[collect_head];
           E->h_group_args[G.off + (s - collect_head)] = a;
           if (--collect_left == 0) {
-            HIPCHECK(hipMemcpyAsync(E->d_group_args + G.off, E->h_group_args.data() + G.off, sizeof(StepArgs) * G.len,
+            HIPCHECK(hipMemcpyAsync(E->d_group_args + G.off, E->h_group_args + G.off, sizeof(StepArgs) * G.len,
                                     hipMemcpyHostToDevice, E->stream));
             G.ready = true;
             const dim3 gg(G.blocks, R, G.len);
@@ -1105,7 +1106,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
       s = e;
     }
     if (total) {
-      E.h_group_args.resize(total);
+      HIPCHECK_X(hipHostMalloc((void**)&E.h_group_args, sizeof(StepArgs) * (size_t)total, hipHostMallocDefault));
       HIPCHECK_X(hipMalloc((void**)&E.d_group_args, sizeof(StepArgs) * (size_t)total));
     } else {
       E.groups.clear();

@@ -903,3 +903,39 @@ def test_grouped_leaf_steps_give_the_same_bits_as_one_launch_each(dtype, monkeyp
     rt, rc = cpu_ref.contract(tn.einsum_str, *tn.params, path=path, split_format=True)
     tol = 1e-4 if dtype == np.float32 else 1e-10
     assert results["grouped"][0] == float(rt) and abs(results["grouped"][1] - float(rc)) <= tol * max(1.0, abs(float(rc)))
+
+
+def test_leaf_group_arguments_built_inside_the_graph_capture(monkeypatch):
+    """Event-timed enqueues send every step out on its own, so when the first two enqueues of an executor are timed
+    the leaf group's arguments are built (and uploaded from pinned memory) by the THIRD one - the one that is being
+    captured into the hipGraph.  Replays must still give the ungrouped bits."""
+    import torch
+
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+    from tests.test_plan_host import _interleaved_peps_path
+
+    rows, cols, bond = 3, 4, 4
+    tn = nets.peps_closed(TN, rows, cols, bond, dtype=np.float32, seed=8)
+    path = ssa_to_linear(_interleaved_peps_path(rows, cols), 2 * rows * cols)
+    shapes = [p.shape for p in tn.params]
+    dev_ops = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in tn.params]
+    got = {}
+    for mode, group in (("grouped", "1"), ("plain", "0")):
+        monkeypatch.setenv("CTN_GROUP", group)
+        E.clear_caches()
+        bc = E.BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=1)
+        out = torch.zeros((1,) + tuple(bc.plan.out_shape), device="cuda")
+        launch = bc.executor.make_enqueue([t.data_ptr() for t in dev_ops], [out[0].data_ptr()])
+        bc.executor.set_timing(2)
+        vals = []
+        for _ in range(6):
+            launch()
+            c = bc.fetch_log_scale()
+            vals.append((float(out[0].cpu()), float(c[0])))
+        assert all(v == vals[0] for v in vals), vals
+        got[mode] = vals[0]
+        del bc
+    E.clear_caches()
+    assert got["grouped"] == got["plain"]
