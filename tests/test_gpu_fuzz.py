@@ -161,3 +161,54 @@ def test_random_large_tile_steps_f64(seed, monkeypatch):
     got = t_hat * np.exp(float(c))
     assert got.shape == ref.shape, einstr
     assert np.max(np.abs(got - ref)) <= 1e-11 * np.max(np.abs(ref)), (einstr, sizes)
+
+
+def _epilogue_sum_case(rng):
+    """Random instance of planner pattern C: a GEMM (row labels from x, column labels from the core, something summed)
+    whose result a network INPUT re-weights and sums over one short column label.  Axis orders of x, of the core and
+    of the output are random; the weights carry a random non-empty subset of the row labels and end in the short
+    label.  Returns (einsum, sizes, short label)."""
+    from contractn_amd import einsum as E
+    for _ in range(2000):
+        rows = list("ab"[:int(rng.integers(1, 3))])
+        cols = list("cd"[:int(rng.integers(1, 3))])
+        ks = list("ef"[:int(rng.integers(1, 3))])
+        batch = ["x"] if rng.random() < 0.25 else []
+        sizes = {l: int(rng.choice([8, 12, 16, 24, 32, 50, 64, 96])) for l in rows + cols}
+        sizes.update({l: int(rng.choice([4, 8, 12, 16, 33])) for l in ks})
+        sizes.update({l: int(rng.choice([2, 3])) for l in batch})
+        sizes["p"] = int(rng.choice([2, 4]))
+        m = int(np.prod([sizes[l] for l in rows])); n = int(np.prod([sizes[l] for l in cols])) * sizes["p"]
+        k = int(np.prod([sizes[l] for l in ks])); b = int(np.prod([sizes[l] for l in batch])) if batch else 1
+        if m < 64 or n < 32 or k < 8 or b * m * n < 65536 or b * m * n > (1 << 22):
+            continue
+        tx = batch + rows + ks; rng.shuffle(tx)
+        tc = batch + cols + ks + ["p"]; rng.shuffle(tc)
+        wrows = [l for l in rows if rng.random() < 0.7] or [rows[0]]
+        rng.shuffle(wrows)
+        tw = wrows + ["p"]
+        out = batch + rows + cols; rng.shuffle(out)
+        einstr = f"{''.join(tx)},{''.join(tc)},{''.join(tw)}->{''.join(out)}"
+        shapes = tuple(tuple(sizes[c] for c in t) for t in (tx, tc, tw))
+        clist = E._contract_path(einstr, shapes, optimize=((0, 1), (0, 1)), memory_limit=None, use_blas=True)
+        infos = E._native_plan(clist, shapes, "float32").step_infos()
+        if infos[0]["kernel"] == 5 and infos[1]["epilogue_sum"] == sizes["p"]:
+            return einstr, sizes
+    raise AssertionError("no epilogue-sum case generated")
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_epilogue_sum_steps_f32(seed):
+    from contractn_amd import einsum as E
+    E.clear_caches()
+    rng = np.random.default_rng(OFFSET + 13000 + seed)
+    einstr, sizes = _epilogue_sum_case(rng)
+    lhs = einstr.split("->")[0].split(",")
+    ops = [(rng.standard_normal([sizes[c] for c in t]) * rng.uniform(0.3, 3.0)).astype(np.float32) for t in lhs]
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    t_hat, c = contract(einstr, *ops, optimize=((0, 1), (0, 1)), split_format=True)
+    got = np.asarray(t_hat, dtype=np.float64) * np.exp(float(c))
+    terms = np.max(np.einsum(einstr, *[np.abs(o).astype(np.float64) for o in ops]))
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 2e-4 * np.max(np.abs(ref)) + 2e-6 * terms, (einstr, sizes)
+    assert abs(np.mean(np.abs(t_hat)) - 1.0) < 1e-5
