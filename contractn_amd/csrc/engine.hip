@@ -48,6 +48,8 @@ struct DevSwitches {
   int mfma_bk = 0;       // CTN_MFMA_BK=16|32: force the k-tile depth of k_mfma_f32
   int group = 1;         // CTN_GROUP=0: never batch independent leaf steps into one launch (k_stream_group)
   int halve = 1;         // CTN_HALVE_TILES=0: never halve the tiles of an under-filled register-staged launch
+  int lat_wg_per_cu_x2 = 2;  // CTN_LAT_WG_X2: twice the workgroups per CU up to which the one-launch latency form is taken
+  int lat_max_t = 64;    // CTN_LAT_MAX_T=32: no 64 x 64 form of the one-launch latency kernel
   int lat64_min_k = 512; // CTN_LAT64_MIN_K: least K for the 64 x 64 one-launch latency form when an operand is k-contiguous
   int splitk = -1;       // CTN_SPLITK: 0 disables the latency mode, 1 forces it for every eligible step (tests)
   int splitk_max = 0;    // CTN_SPLITK_MAX: tile-count threshold of the latency mode
@@ -67,6 +69,8 @@ static DevSwitches read_dev_switches() {
   d.splitk_max = num("CTN_SPLITK_MAX", 0);
   d.lat = num("CTN_LAT", -1);
   d.lat64_min_k = num("CTN_LAT64_MIN_K", 512);
+  d.lat_max_t = num("CTN_LAT_MAX_T", 64);
+  d.lat_wg_per_cu_x2 = num("CTN_LAT_WG_X2", 2);
   d.halve = num("CTN_HALVE_TILES", 1);
   d.group = num("CTN_GROUP", 1);
   d.g_no_asm = getenv("CTN_G_NO_ASM") != nullptr;
@@ -261,8 +265,14 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSw
   const int64_t limit = max_tiles > 0 ? max_tiles : n_cu / 2;
   if (mode != 1 && (int64_t)st.blocks * R > limit) return 0;
   const int64_t tiles64 = st.Bt * ((st.M + 63) / 64) * ((st.N + 63) / 64) * R;
+  // 64 x 64 tiles that already give every CU a workgroup run un-split on the register-staged kernel: two K slabs plus
+  // the reduce pass lose to it (7 replicas of 256 x 1024 x 256: 5.3 ms per 100-site network against 4.35 at 8)
+  if (tiles64 >= n_cu && mode != 1) return 0;
   int64_t S = (2 * (int64_t)n_cu + tiles64 - 1) / tiles64;   // aim at ~2 small workgroups per CU
   S = std::max<int64_t>(1, std::min<int64_t>(S, st.K / 64));
+  // one split is no split: the register-staged kernel on halved tiles does the same work without slab and reduce pass
+  // (8 replicas of a 256 x 1024 x 256 step; CTN_SPLITK=1 keeps it for the tests)
+  if (S <= 1 && mode != 1) return 0;
   return (int)S;
 }
 
@@ -281,19 +291,24 @@ static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitche
   if (sw.lat != 1 && ((int64_t)st.blocks * R > n_cu / 2 || st.K < 128)) return 0;
   auto tiles = [&](int T) { return st.Bt * ((st.M + T - 1) / T) * ((st.N + T - 1) / T); };
   const int64_t t16 = tiles(16), t32 = tiles(32), t64 = tiles(64);
-  // ... and not more than ~1.5 workgroups per CU: beyond that split-K with its LDS-staged 64 x 64 tiles wins
-  // (100-site D = 256 network: R = 4 3.49 vs 4.21 ms for split-K, R = 8 5.83 vs 5.05 ms)
-  auto fits = [&](int64_t t) { return t <= kLatMaxTiles && (sw.lat == 1 || 2 * t * R <= 3LL * n_cu); };
+  // ... and not more than one workgroup per CU (a second round of 512-thread workgroups doubles the step): beyond
+  // that split-K / halved register-staged tiles win (100-site D = 256 network, R = 4: 3.49 vs 4.23 ms; R = 5: 5.33 vs
+  // 4.61; R = 6: 5.55 vs 4.79; R = 8: 5.83 vs 4.37)
+  auto fits = [&](int64_t t) { return t <= kLatMaxTiles && (sw.lat == 1 || t * R <= (int64_t)n_cu * sw.lat_wg_per_cu_x2 / 2); };
   if (f64) return fits(t16) ? 16 : 0;     // fp64: 16 x 16 tiles (v_mfma_f64_16x16x4_f64) only
   // (a k-contiguous operand reaches the fragment registers as 4-byte loads a row stride apart; with a short K split
   // eight ways there is nothing to pipeline them behind: 1024 x 1024 x 256, A k-contiguous, took 27.8 us on 256 tiles
   // of 64 x 64 against 23.7 us for the LDS-staged tiles with two K slabs - while the same tile count with both
   // operands row-contiguous, 4 x (256 x 1024 x 256), is 6 % faster here than there)
   const bool kcontig = st.modeA == 2 || st.modeB == 2;
-  if (t64 * R >= n_cu && fits(t64) && st.K <= 2 * 512 && (!kcontig || st.K >= sw.lat64_min_k)) return 64;
+  // (... and with K = 1024 the plain 64 x 64 tiles win: 16 replicas of 256 x 256 x 1024, 7.53 -> 7.03 ms per network)
+  if (sw.lat_max_t >= 64 && t64 * R >= n_cu && fits(t64) && st.K <= 512 && (!kcontig || st.K >= sw.lat64_min_k)) return 64;
   if (t32 * R >= n_cu && fits(t32)) return 32;
   if (fits(t16)) return 16;
   if (fits(t32)) return 32;
+  // half the CUs busy with 64 x 64 tiles still beats four K slabs plus a reduce pass (2 / 3 replicas of
+  // 256 x 1024 x 256: 3.47 -> 3.28 / 3.62 -> 3.44 ms per 100-site network)
+  if (sw.lat_max_t >= 64 && 2 * t64 * R >= n_cu && fits(t64) && st.K <= 256 && !kcontig) return 64;   // (a long K is better off split over workgroups)
   return 0;
 }
 

@@ -401,7 +401,7 @@ def test_latency_mode_split_k(dtype, tol, einstr, shapes, monkeypatch):
     ("kam,kbn->ambn", [(136, 4, 24), (136, 2, 40)], 1, (16, 16)),  # composite free indices, strided C
     ("km,kn->mn", [(4096, 64), (4096, 64)], 1, (16, 16)),      # K = 4096: both tables fill their LDS arrays
     ("km,kn->mn", [(130, 256), (130, 256)], 4, (32, 32)),      # 4 x 64 tiles of 32: odd k chunk (17 -> 18)
-    ("km,kn->mn", [(130, 512), (130, 512)], 5, (64, 64)),      # 5 x 64 tiles of 64: k chunk 65 -> 66
+    ("km,kn->mn", [(130, 512), (130, 512)], 4, (64, 64)),      # 4 x 64 tiles of 64 (one per CU): k chunk 65 -> 66
 ])
 def test_latency_mode_one_launch(einstr, shapes, replicas, tile):
     """A few networks in flight, fp32: the step runs as ONE launch of k_mfma_f32_lat - K split over the eight waves
