@@ -407,7 +407,9 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
   constexpr int NI = BM / 64;
   // one LDS object: [A buf0][A buf1][B buf0][B buf1][omC BM][onC TN][red 4 doubles]; the operand buffers double as
   // the epilogue's per-wave staging area (32 rows x TN/2 columns each), which for the 64-row tile is the larger of the two
-  constexpr int BUF = (2 * SZA + 2 * SZB > 4 * 32 * (TN / 2) ? 2 * SZA + 2 * SZB : 4 * 32 * (TN / 2) + 3) & ~3;
+  // (the 64-row tile stages 16 rows at a time: 25 KB instead of 33 KB of LDS, five workgroups per CU instead of four)
+  constexpr int SR = BM == 64 ? 16 : 32;           // rows a wave stages per epilogue pass
+  constexpr int BUF = (2 * SZA + 2 * SZB > 4 * SR * (TN / 2) ? 2 * SZA + 2 * SZB : 4 * SR * (TN / 2) + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float smem[BUF + BM + TN + 8 + (EPW ? 5 * BM : 0)];
   float* sA = smem;
   float* sB = smem + 2 * SZA;
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
     // operations of one wave execute in order, so the write -> read hand-off is wave-local.
     constexpr int WT = TN / 2;                       // columns owned by a wave
     constexpr int LDSW = (BUF / 4) & ~3;             // floats of LDS per wave (16-byte aligned)
-    static_assert(LDSW >= 32 * WT, "per-wave staging area too small");
+    static_assert(LDSW >= SR * WT, "per-wave staging area too small");
     constexpr int VW = WT / 4;                       // 16-byte vectors per row
     constexpr int RPI = 64 / VW;                     // rows covered by one wave-wide vector access
     float* wC = smem + w * LDSW;                     // [32][WT]
@@ -520,17 +522,18 @@ __global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void k_mfma_f32(StepArgs a
     const bool cin = n0 + gcol < a.N;  // N % 4 == 0 whenever c_vec, otherwise checked per element
     const int offn = s_onC[gcol];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
+    for (int ih = 0; ih < NI * (32 / SR); ++ih) {
+      const int i = ih / (32 / SR), half = ih % (32 / SR);   // accumulator registers e: rows (e & 3) + 8 (e >> 2) + 4 h
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          wC[((e & 3) + 8 * (e >> 2) + 4 * h) * WT + j * 32 + l31] = (acc[i][j][e] * iA) * iB;
+        for (int e = half * (SR / 2); e < half * (SR / 2) + SR / 2; ++e)
+          wC[((e & 3) + 8 * (e >> 2) + 4 * h - half * SR) * WT + j * 32 + l31] = (acc[i][j][e] * iA) * iB;
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int it = 0; it < 32 / RPI; ++it) {
+      for (int it = 0; it < SR / RPI; ++it) {
         const int lrow = it * RPI + lane / VW;
-        const int row = wm + i * 32 + lrow;
+        const int row = wm + i * 32 + half * SR + lrow;
         const float4 v = *reinterpret_cast<const float4*>(wC + lrow * WT + c4);
         if constexpr (EPW) {
           const int P = a.epw & 0xFF;
