@@ -939,3 +939,36 @@ def test_leaf_group_arguments_built_inside_the_graph_capture(monkeypatch):
         del bc
     E.clear_caches()
     assert got["grouped"] == got["plain"]
+
+
+def test_epilogue_sum_and_grouped_leaves_in_eager_rescale_mode():
+    """Eager mode normalises every intermediate in place right after its step: an epilogue-summed step must then see
+    scale 1 on its operands and have ITS output (the summed one) renormalised; leaf groups fall back to one launch
+    per step.  Same numbers as the lazy default, to rounding - a batched MPS (pattern C) and an interleaved PEPS."""
+    from contractn_amd import TN, engine
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+    from tests.test_plan_host import _interleaved_peps_path
+
+    E.clear_caches()
+    tn, inputs = nets.batched_mps(TN, 6, 64, 4, 512, dtype=np.float32, seed=4)
+    ops = E.make_arg_packer(tn)(tn.params, inputs)
+    cases = [(tn.einsum_str, [np.asarray(o) for o in ops], ssa_to_linear(nets.batched_mps_path(6), 12))]
+    tp = nets.peps_closed(TN, 3, 4, 4, dtype=np.float32, seed=6)
+    cases.append((tp.einsum_str, list(tp.params), ssa_to_linear(_interleaved_peps_path(3, 4), 24)))
+    for einstr, operands, path in cases:
+        shapes = tuple(o.shape for o in operands)
+        clist = E._contract_path(einstr, shapes, optimize=path, memory_limit=None, use_blas=True)
+        plan = E._native_plan(clist, shapes, "float32")
+        lazy, eager = engine.Executor(plan), engine.Executor(plan)
+        eager.set_rescale_mode(1)
+        for ex in (lazy, eager, eager):                      # (the second eager run: nothing is left over from the first)
+            o, _l, r = ex.run_host([operands])
+            c = float(E.accumulate_log_scale(r[0], np.dtype(np.float32)))
+            val = o[0].astype(np.float64) * np.exp(c)
+            if ex is lazy:
+                ref = val
+        assert lazy.eager_reruns() == 0 and eager.eager_reruns() == 0
+        assert np.max(np.abs(val - ref)) <= 2e-5 * np.max(np.abs(ref)), einstr
+        lazy.close(); eager.close()
+    E.clear_caches()
