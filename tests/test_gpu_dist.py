@@ -284,3 +284,23 @@ def test_two_ranks_batch_sharded_classifier_outputs():
         assert np.max(np.abs(got - one)) <= 1e-5 * np.max(np.abs(one))
         assert abs(np.mean(np.abs(t)) - 1.0) < 1e-5
     assert np.array_equal(results[0][1], results[1][1]) and results[0][2] == results[1][2]
+
+
+def test_bench_default_two_ranks_rehearsal():
+    """The driver's multi-GPU launch of the DEFAULT bench (`torch.distributed.run ... bench.py --gpus N`), rehearsed
+    with two ranks on cuda:0 over gloo at a small size: the weak-scaling headline line plus both secondaries - the
+    batched MPS (data-parallel over the batch) and the PEPS sharded over the ranks - must come back without an error."""
+    env = dict(os.environ, CTN_BENCH_BACKEND="gloo", CTN_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--sites", "12", "--bond", "64", "--replicas", "8", "--peps-bonds", "8"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["replicas_per_gpu"] == 8
+    b = line["batched_mps"]
+    assert "error" not in b and b["scaling"] == "weak" and b["value"] > 0 and b["epilogue_summed_steps"] == 10
+    p = line["peps_strong_scaling"]["D8"]
+    assert "error" not in p and p["scaling"] == "strong" and p["config"]["slices_per_gpu"] * 2 == p["config"]["slices"]
+    assert p["result"]["t_hat"] in (1.0, -1.0) and np.isfinite(p["result"]["log_scale"])
