@@ -50,6 +50,7 @@ struct DevSwitches {
   int halve = 1;         // CTN_HALVE_TILES=0: never halve the tiles of an under-filled register-staged launch
   int lat_wg_per_cu_x2 = 2;  // CTN_LAT_WG_X2: twice the workgroups per CU up to which the one-launch latency form is taken
   int lat_max_t = 64;    // CTN_LAT_MAX_T=32: no 64 x 64 form of the one-launch latency kernel
+  int splitk_fill_long = 2;  // CTN_SPLITK_FILL_LONG: K >= 1024 steps are split until 64 x 64 tiles give this many workgroups per CU
   int lat64_min_k = 512; // CTN_LAT64_MIN_K: least K for the 64 x 64 one-launch latency form when an operand is k-contiguous
   int splitk = -1;       // CTN_SPLITK: 0 disables the latency mode, 1 forces it for every eligible step (tests)
   int splitk_max = 0;    // CTN_SPLITK_MAX: tile-count threshold of the latency mode
@@ -69,6 +70,7 @@ static DevSwitches read_dev_switches() {
   d.splitk_max = num("CTN_SPLITK_MAX", 0);
   d.lat = num("CTN_LAT", -1);
   d.lat64_min_k = num("CTN_LAT64_MIN_K", 512);
+  d.splitk_fill_long = num("CTN_SPLITK_FILL_LONG", 2);
   d.lat_max_t = num("CTN_LAT_MAX_T", 64);
   d.lat_wg_per_cu_x2 = num("CTN_LAT_WG_X2", 2);
   d.halve = num("CTN_HALVE_TILES", 1);
@@ -266,8 +268,9 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSw
   if (mode != 1 && (int64_t)st.blocks * R > limit) return 0;
   const int64_t tiles64 = st.Bt * ((st.M + 63) / 64) * ((st.N + 63) / 64) * R;
   // 64 x 64 tiles that already give every CU a workgroup run un-split on the register-staged kernel: two K slabs plus
-  // the reduce pass lose to it (7 replicas of 256 x 1024 x 256: 5.3 ms per 100-site network against 4.35 at 8)
-  if (tiles64 >= n_cu && mode != 1) return 0;
+  // the reduce pass lose to it (7 replicas of 256 x 1024 x 256: 5.3 ms per 100-site network against 4.35 at 8) - a long
+  // K (>= 1024) is still worth two slabs up to two workgroups per CU (16 x (256 x 256 x 1024): 7.02 -> 6.20 ms)
+  if (tiles64 >= (int64_t)n_cu * (st.K >= 1024 ? sw.splitk_fill_long : 1) && mode != 1) return 0;
   int64_t S = (2 * (int64_t)n_cu + tiles64 - 1) / tiles64;   // aim at ~2 small workgroups per CU
   S = std::max<int64_t>(1, std::min<int64_t>(S, st.K / 64));
   // one split is no split: the register-staged kernel on halved tiles does the same work without slab and reduce pass
