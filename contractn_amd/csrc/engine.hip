@@ -323,10 +323,15 @@ static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitche
 static bool g_launch(const Step& st, int R, int n_cu, int use_g) {
   // does a launch of this (planner-eligible) step take the large-tile LDS-DMA kernel?  At least two of the big tiles
   // per CU and K >= 192 (below that the 128-tile kernel's 3-4 workgroups per CU hide the per-tile cost better), or a
-  // long K (>= 1024) from 3/4 of a tile per CU; CTN_MFMA_G=2: whenever eligible (tests)
+  // long K (>= 1024) from 7/8 of a tile per CU; CTN_MFMA_G=2: whenever eligible (tests)
   if (!use_g || st.kernel != CTN_KERNEL_MFMA_F32 || st.tileM != 256) return false;
   const int64_t gtiles = st.Bt * ((st.M + 255) / 256) * ((st.N + st.tileN - 1) / st.tileN) * R;
-  return use_g >= 2 || (gtiles >= 2LL * n_cu && st.K >= 192) || (st.K >= 1024 && 4 * gtiles >= 3LL * n_cu);
+  if (use_g >= 2 || (gtiles >= 2LL * n_cu && st.K >= 192)) return true;
+  // ... below two tiles per CU a long K still pays, provided the tiles divide evenly over the CUs: 320 tiles are two
+  // rounds on 64 CUs and one on the rest (100-site network: 160 replicas 42.8 ms against 39.7 on 128-wide tiles; 96
+  // replicas = 192 tiles 25.2 against 23.1; 112 = 224 tiles 28.4 against 29.7, 128 = 256 tiles 29.0 against 29.1)
+  const int64_t rounds = (gtiles + n_cu - 1) / n_cu;
+  return st.K >= 1024 && 4 * gtiles >= 3LL * n_cu && 100 * gtiles >= 85 * rounds * n_cu;
 }
 
 static void plain_tiles(const Step& st, int R, int n_cu, int use_g, bool is_last, int* tm, int* tn, int halve = 1) {
