@@ -159,3 +159,52 @@ def test_cfg5_peps_8x8_bond8_three_routes_one_value():
     t_j, c_j = dist.combine_split(parts)
     assert float(t_j) == float(t_r) and abs(float(c_j) - float(c_r)) <= 1e-3
     E.clear_caches()
+
+
+# ---- config 3b: the paper's ML workload at its full size --------------------------------------------------------------
+def test_cfg3b_full_size_batched_mps_vs_oracle_on_a_subset_of_the_batch():
+    """4096 inputs through ONE 100-site MPS (D = 256, d = 4) hanging on a batch hyperedge (BASELINE configs[2] in its
+    batched form, SURVEY.md 8d cfg 3b; 212 GFLOP): every interior site is one launch (`epilogue_sum`), nothing larger
+    than B x D is ever stored, and - batch independence - outputs 0..31 and 4064..4095 equal the CPU oracle run on
+    those 64 inputs alone (same path), to the north_star's fp32 tolerance."""
+    import torch
+
+    from tests import networks as nets
+
+    B, n_sites, bond, phys = 4096, 100, 256, 4
+
+    class Shape:
+        def __init__(self, shape):
+            self.shape, self.ndim = tuple(shape), len(shape)
+
+    tn = TN()
+    hub = tn.add_copy_node(n_sites + 1)
+    cores = [Shape((phys, bond) if i in (0, n_sites - 1) else (phys, bond, bond)) for i in range(n_sites)]
+    nodes = nets.add_mps(tn, cores)
+    for i, node in enumerate(nodes):
+        inp = tn.add_input_node((B, phys), var_shape_axes=(0,))
+        tn.connect_nodes(inp, node, 1, 0)
+        tn.connect_nodes(hub, inp, i, 0)
+    shapes = [c.shape for c in cores] + [(B, phys)] * n_sites
+    path = ssa_to_linear(nets.batched_mps_path(n_sites), 2 * n_sites)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(21)
+    ops = [torch.randn(s, generator=gen, device="cuda") / 4.0 for s in shapes]
+    clist = E._contract_path(tn.einsum_str, tuple(shapes), optimize=path, memory_limit=None, use_blas=True)
+    infos = E._native_plan(clist, tuple(shapes), "float32").step_infos()
+    assert sum(i["epilogue_sum"] == phys for i in infos) == n_sites - 2
+    assert max(i["out_numel"] for i in infos if i["kernel"] != 5) <= B * bond
+    t, c = contract(tn.einsum_str, *ops, optimize=path, split_format=True)
+    assert t.is_cuda and tuple(t.shape) == (B,) and abs(float(t.abs().mean()) - 1.0) < 1e-4
+    got = t.double().cpu().numpy() * np.exp(float(c))
+    rows = np.r_[0:32, B - 32:B]
+    h_ops = [o[rows].cpu().numpy() if tuple(o.shape) == (B, phys) else o.cpu().numpy() for o in ops]
+    rt, rc = cpu_ref.contract(tn.einsum_str, *h_ops, path=list(path), split_format=True)
+    ref = np.asarray(rt, dtype=np.float64) * np.exp(float(rc))
+    assert np.max(np.abs(got[rows] - ref)) <= 1e-3 * np.max(np.abs(ref))
+    # the same contraction again: identical bits (fixed-order reductions)
+    t2, c2 = contract(tn.einsum_str, *ops, optimize=path, split_format=True)
+    assert torch.equal(t2, t) and float(c2) == float(c)
+    del ops, t, t2
+    torch.cuda.empty_cache()
+    E.clear_caches()
