@@ -38,7 +38,9 @@ typedef enum {
   CTN_OK = 0,
   CTN_INVALID_ARG = -1,    /* -> TypeError / AssertionError on the Python side */
   CTN_SHAPE_MISMATCH = -2, /* -> ValueError */
-  CTN_UNSUPPORTED = -3,    /* -> NotImplementedError */
+  CTN_UNSUPPORTED = -3,    /* -> NotImplementedError: a dtype other than f32 / f64, or a MATERIALISED tensor (input, step
+                              output) or index group of 2^31 or more elements - offset tables are int32; a product
+                              that large can still be formed on the fly inside the step that consumes it */
   CTN_OOM = -4,            /* -> MemoryError */
   CTN_HIP_ERROR = -5,      /* -> RuntimeError */
   CTN_RCCL_ERROR = -6,     /* reserved: collectives are issued by the host layer */
