@@ -265,7 +265,7 @@ def peps_secondary(args, result, world, rank, local_rank, backend, dev):
     dog.daemon = True
     dog.start()
     try:
-        for bond, slices, max_int, steps, warmup in ((8, 64, None, 10, 2), (16, 64, 2 ** 28, 1, 1)):
+        for bond, slices, max_int, steps, warmup in ((8, 64, None, 20, 3), (16, 64, 2 ** 28, 1, 1)):
             if bond not in args.peps_bonds:
                 continue
             a2 = copy.copy(args)
