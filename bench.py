@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--max-intermediate", type=int, default=None,
                     help="peps: slice until no intermediate has more elements than this")
     ap.add_argument("--workspace-gib", type=float, default=64.0, help="peps: workspace budget per GPU for slices in flight")
+    ap.add_argument("--single-gpu-reference", action="store_true",
+                    help="peps: rank 0 also measures the best single-GPU form of the same network (unsliced where it fits, "
+                         "and the sliced plan on one GPU) and the line reports the speed-up against it")
     ap.add_argument("--no-peps", dest="with_peps", action="store_false",
                     help="mps: skip the secondary PEPS strong-scaling measurement that follows the headline")
     ap.add_argument("--peps-bonds", type=int, nargs="*", default=[8, 16], help="mps: bond dimensions of that secondary")
@@ -60,6 +63,7 @@ def parse_args():
     ap.add_argument("--bond", type=int, default=None, help="bond dimension (default: 256 for mps, 8 for peps)")
     ap.add_argument("--phys", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="mps: skip the R = 1 / 8 / 64 networks-in-flight figures")
     ap.add_argument("--streams", type=int, default=1,
                     help="split the replicas into this many groups, each on its own HIP stream")
     ap.add_argument("--event-passes", type=int, default=3, help="timed passes bracketed by HIP events")
@@ -97,9 +101,7 @@ def init_ranks(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but the launcher started {world} ranks"
     # rehearsal knobs (one-GPU box): CTN_BENCH_BACKEND=gloo + CTN_BENCH_ONE_DEVICE=1 run all ranks on cuda:0
     backend = os.environ.get("CTN_BENCH_BACKEND", "nccl")
     if os.environ.get("CTN_BENCH_ONE_DEVICE"):
@@ -118,8 +120,29 @@ def init_ranks(args):
     return world, rank, local_rank, backend, torch.device("cuda", local_rank)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD
+    `python -m torch.distributed.run ... bench.py <same arguments>` (one process per GPU, rendezvous on 127.0.0.1),
+    pass its output through and return its exit code.  Called before anything has touched the GPU - this process
+    never does - and never replaces itself: the ranks are children, the parent only waits."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -245,8 +268,8 @@ def peps_secondary(args, result, world, rank, local_rank, backend, dev):
     """After the headline measurement, the SAME launch also contracts the 8 x 8 PEPS of BASELINE config 5 sharded
     over all its ranks (`--config peps` in short form: D = 8 with 64 slices, D = 16 with 256), so that a run at
     N = 1, 2, 4, 8 GPUs leaves the strong-scaling figures of the index-sliced path next to the weak-scaling
-    headline.  It never endangers the headline line: errors are recorded in the object, and a watchdog thread
-    prints the line and ends the process if a rank gets stuck in a collective."""
+    headline.  It never loses the headline line: errors are recorded in the object, and a watchdog thread prints
+    the line and ends the process - with a non-zero exit code - if a rank gets stuck in a collective."""
     import copy
     import threading
 
@@ -256,10 +279,13 @@ def peps_secondary(args, result, world, rank, local_rank, backend, dev):
     out = result.setdefault("peps_strong_scaling", {}) if rank == 0 else {}
 
     def give_up():
+        # a rank stuck in a kernel or a collective: the headline line (already measured) is still printed, but the
+        # process ends NON-ZERO on every rank, so that the hang is investigated instead of being read as a clean run
         if rank == 0:
-            out["error"] = f"watchdog: not finished after {args.peps_timeout:.0f}s"
+            out["error"] = (f"watchdog: secondary not finished after {args.peps_timeout:.0f}s; every rank exits "
+                            f"non-zero (rank 0 with 4, the others with 3)")
             print(json.dumps(result), flush=True)
-        os._exit(0 if rank == 0 else 3)
+        os._exit(4 if rank == 0 else 3)
 
     dog = threading.Timer(args.peps_timeout, give_up)
     dog.daemon = True
@@ -271,12 +297,14 @@ def peps_secondary(args, result, world, rank, local_rank, backend, dev):
             a2 = copy.copy(args)
             a2.rows, a2.cols, a2.bond, a2.slices, a2.max_intermediate = 8, 8, bond, slices, max_int
             a2.steps, a2.warmup, a2.no_cpu_baseline, a2.dump_steps, a2.event_passes = steps, warmup, True, None, 1
+            a2.single_gpu_reference = True
             try:
                 full = run_peps(a2, world, rank, local_rank, backend, dev)
             except Exception as exc:  # noqa: BLE001 - recorded, the headline line must still be printed
                 full = {"error": repr(exc)}
             if rank == 0:
-                keep = ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "achieved_tflops", "result", "error")
+                keep = ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "achieved_tflops", "result", "error",
+                        "strong_scaling")
                 short = {k: full[k] for k in keep if k in full}
                 if "config" in full:
                     short["config"] = {k: full["config"][k] for k in ("workload", "slices", "slices_per_gpu",
@@ -467,6 +495,11 @@ def run_mps(args, world, rank, local_rank, backend, dev):
         roofline["peak_at_measured_clock"] = round(at_clock, 1)
         roofline["frac_at_measured_clock"] = round(achieved / at_clock, 4)
 
+    # ---- a few networks in flight (SURVEY.md 8d cfg 3a: R in {1, 8, 64}; H1: "report R = 1 latency and R >> 1
+    # throughput"): the same network, path and tensors, R of the replicas above per launch sequence, rank 0 ----
+    if rank == 0 and not args.no_latency:
+        result["latency"] = few_in_flight(args, einstr, shapes, path, np_dt, in_ptrs, out_ptrs, n_in, local_rank, plan.flops, peak)
+
     # ---- CPU baseline: the oracle on the same network and path (rank 0, N=1 only) --------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(einstr, shapes, path, flat[0], offs, numels, args.cpu_seconds,
@@ -477,6 +510,38 @@ def run_mps(args, world, rank, local_rank, backend, dev):
             pv["last_replica"] = extra["parity_vs_gpu"]
             pv["ok"] = bool(pv["ok"] and extra["parity_vs_gpu"]["ok"])
     return result if rank == 0 else None
+
+
+def few_in_flight(args, einstr, shapes, path, np_dt, in_ptrs, out_ptrs, n_in, device, flops, peak):
+    """ms per pass and TFLOP/s with R = 1, 8 and 64 networks in flight (three short timed loops after the headline,
+    outside its timed region; hipGraph replay like the headline).  One network of this dependent chain cannot fill
+    256 CUs: R = 1 is a latency figure, the headline's R is the throughput figure."""
+    from contractn_amd.einsum import BatchedContraction
+
+    out = {"unit": "ms per pass of R networks", "passes": None, "by_R": {}}
+    try:
+        for R in (1, 8, 64):
+            if R > len(out_ptrs):
+                break
+            bc = BatchedContraction(einstr, shapes, np_dt, optimize=path, replicas=R, device=device)
+            launch = bc.executor.make_enqueue(in_ptrs[:R * n_in], out_ptrs[:R])
+            for _ in range(4):
+                launch()
+            bc.executor.synchronize()
+            reps = 20 if R < 64 else 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                launch()
+            bc.executor.synchronize()
+            sec = (time.perf_counter() - t0) / reps
+            out["by_R"][str(R)] = {"ms": round(sec * 1e3, 4), "contractions_per_s": round(R / sec, 1),
+                                   "tflops": round(R * flops / sec / 1e12, 2),
+                                   "frac_of_mfma_peak": round(R * flops / sec / 1e12 / peak, 4)}
+            out["passes"] = reps
+            bc.executor.close()
+    except Exception as exc:  # noqa: BLE001 - recorded, the headline line must still be printed
+        out["error"] = repr(exc)
+    return out
 
 
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E peak (spec)
@@ -656,7 +721,78 @@ def run_peps(args, world, rank, local_rank, backend, dev):
         result["cpu_baseline"] = peps_cpu_baseline(sc, einstr, ops, labels, path, args.cpu_seconds)
         if rep["unsliced_largest_intermediate"] <= 2 ** 28:
             result["unsliced_check"] = peps_unsliced_check(einstr, shapes, ops, float(t_hat), float(log_scale), local_rank)
+    if getattr(args, "single_gpu_reference", False):
+        del sc, ex
+        torch.cuda.empty_cache()
+        result["strong_scaling"] = peps_single_gpu_reference(args, einstr, shapes, ops, labels, path, rep, local_rank,
+                                                             world, elapsed / args.steps, float(t_hat), float(log_scale))
     return result
+
+
+def peps_single_gpu_reference(args, einstr, shapes, ops, labels, path, rep, device, world, sec_per_step, t_hat, log_scale):
+    """What ONE GPU does best on the same network, measured by rank 0 in the same run (the other ranks wait), so
+    that the strong-scaling figure is quoted against the best single-GPU time and not only against the sliced
+    plan run on one GPU: (a) the network UNSLICED on the library's own path where its largest intermediate fits
+    (8 x 8, D = 8: 2^27 elements); (b) the sliced plan with all slices on one GPU (what N = 1 of this benchmark
+    runs; for D = 16, whose unsliced peak is 2^36 elements, the only single-GPU form).  Both values are checked
+    against the sharded result (1e-3)."""
+    import torch
+
+    from contractn_amd import dist as cdist
+    from contractn_amd.einsum import BatchedContraction
+
+    dev = torch.device("cuda", device)
+    out = {"n_gpus": world, "ms_per_contraction": round(sec_per_step * 1e3, 4)}
+
+    def agrees(t1, c1):
+        return bool(abs(np.exp(c1 - log_scale) * (t1 * t_hat) - 1.0) <= 1e-3)
+
+    if world == 1:
+        sliced_ms = sec_per_step * 1e3
+    else:
+        sc1 = cdist.SlicedContraction(einstr, ops, labels, optimize=path, rank=0, world=1, device=device,
+                                      workspace_budget=int(args.workspace_gib * 2 ** 30))
+        reps = 1 if sec_per_step * world > 1.0 else max(3, args.steps)
+        for _ in range(0 if reps == 1 else 3):
+            sc1.run()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            t1, c1 = sc1.run()
+        torch.cuda.synchronize(dev)
+        sliced_ms = (time.perf_counter() - t0) / reps * 1e3
+        out["sliced_single_gpu_agrees"] = agrees(float(t1), float(c1))
+        del sc1
+        torch.cuda.empty_cache()
+    out["sliced_single_gpu_ms"] = round(sliced_ms, 4)
+    best_ms, best = sliced_ms, "sliced plan, all slices on one GPU"
+    if rep["unsliced_largest_intermediate"] <= 2 ** 28:
+        bc = BatchedContraction(einstr, shapes, np.float32, optimize="auto", replicas=1, device=device)
+        d_ops = [torch.as_tensor(o, device=dev) for o in ops]
+        res = torch.zeros(1, device=dev)
+        torch.cuda.synchronize(dev)
+        launch = bc.executor.make_enqueue([t.data_ptr() for t in d_ops], [res.data_ptr()])
+        for _ in range(3):
+            launch()
+        bc.executor.synchronize()
+        reps = max(5, args.steps)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            launch()
+        bc.executor.synchronize()
+        unsliced_ms = (time.perf_counter() - t0) / reps * 1e3
+        c_u = float(bc.fetch_log_scale()[0])
+        out["unsliced_single_gpu_ms"] = round(unsliced_ms, 4)
+        out["unsliced_single_gpu_agrees"] = agrees(float(res.cpu()[0]), c_u)
+        out["unsliced_flop"] = bc.plan.flops
+        if unsliced_ms < best_ms:
+            best_ms, best = unsliced_ms, "unsliced, the library's own path (`auto`)"
+        bc.executor.close()
+    out["best_single_gpu_ms"] = round(best_ms, 4)
+    out["best_single_gpu"] = best
+    out["speedup_vs_best_single_gpu"] = round(best_ms / (sec_per_step * 1e3), 3)
+    out["speedup_vs_sliced_single_gpu"] = round(sliced_ms / (sec_per_step * 1e3), 3)
+    return out
 
 
 def peps_cpu_baseline(sc, einstr, ops, labels, path, budget_s):
@@ -672,6 +808,7 @@ def peps_cpu_baseline(sc, einstr, ops, labels, path, budget_s):
         threads = max((p.get("num_threads", 1) for p in threadpool_info()), default=1)
     except Exception:
         threads = os.cpu_count()
+    sc.local_result()                 # per-slice values through the checked host path (run() joins on the device)
     gpu_t, gpu_c = sc.last_slices
     n, worst, signs_ok, spent, clist = 0, 0.0, True, 0.0, None
     for i, (_vals, sliced_str, sl_ops) in enumerate(cdist.slice_network(einstr, ops, labels)):
@@ -844,6 +981,25 @@ def cpu_baseline(einstr, shapes, path, flat0, offs, numels, budget_s, gpu_t, gpu
     ops = [host[int(offs[i]): int(offs[i]) + numels[i]].reshape(shapes[i]) for i in range(len(shapes))]
     clist = cpu_ref.contraction_list(einstr, shapes, path)
     t_ref, c_ref, _ = cpu_ref.core_contract(ops, clist)  # warm-up + parity sample
+    # the CPU's best, not its default: the zipper's GEMMs are small (256 x 256 x 1024), and all 128 OpenBLAS threads
+    # of a GPU box oversubscribe them - one contraction per candidate thread count, then the budget on the best
+    sweep, limit = {}, None
+    if budget_s > 0:
+        try:
+            from threadpoolctl import threadpool_limits
+
+            for nt in (8, 16, 32, 64, 128):
+                if nt > max(threads, 8):
+                    break
+                with threadpool_limits(limits=nt, user_api="blas"):
+                    t0 = time.perf_counter()
+                    cpu_ref.core_contract(ops, clist)
+                    sweep[nt] = round(1.0 / (time.perf_counter() - t0), 3)
+            if sweep:
+                threads = max(sweep, key=sweep.get)
+                limit = threadpool_limits(limits=threads, user_api="blas")
+        except Exception:   # noqa: BLE001 - no threadpoolctl: the library's default thread count, as before
+            sweep, limit = {}, None
     n, t0 = 0, time.perf_counter()
     while True:
         cpu_ref.core_contract(ops, clist)
@@ -851,6 +1007,8 @@ def cpu_baseline(einstr, shapes, path, flat0, offs, numels, budget_s, gpu_t, gpu
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 50:
             break
+    if limit is not None:
+        limit.restore_original_limits()
     # a scalar in split format is (+-1, log|value|): the sign must match exactly and the value's relative error is
     # |dc| itself (north_star: 1e-3 for fp32, 1e-6 for fp64; asserted an order tighter)
     tol = 1e-7 if f64 else 1e-4
@@ -862,7 +1020,8 @@ def cpu_baseline(einstr, shapes, path, flat0, offs, numels, budget_s, gpu_t, gpu
         "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"{n} full contractions of replica 0 (same 100-site network, same zipper path, "
-                  f"NumPy/OpenBLAS) in {dt:.1f}s",
+                  f"NumPy/OpenBLAS) in {dt:.1f}s on the best of the BLAS thread counts tried",
+        "contractions_per_s_by_blas_threads": sweep,
         "parity_vs_gpu": {"ok": bool(ok), "tolerance_abs_log": tol, "gpu": [gpu_t, gpu_c],
                           "cpu": [float(t_ref), float(c_ref)]},
     }

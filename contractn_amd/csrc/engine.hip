@@ -154,8 +154,9 @@ struct Exec {
   // switches to eager by itself, and repeats the contraction, when the scale registers of a finished run show
   // that a lazy product left the dtype's range (exec_scales_suspect); it then stays eager.
   bool eager_rescale = false;
-  bool eager_forced = false;        // ctn_exec_set_rescale_mode(1)
+  bool eager_forced = false;        // ctn_exec_set_rescale_mode(1): every run eager; otherwise lazy is tried first
   int eager_reruns = 0;
+  int eager_streak = 0;             // consecutive runs that had to be repeated eagerly (see exec_new_run)
   std::vector<double> h_resc;       // host copy of the last run's per-step rescale factors [R][n_steps]
   // Grouped leaf steps: runs of consecutive streaming steps whose operands are all network inputs (independent of
   // each other and of everything before them) go out as ONE launch of k_stream_group; their arguments never
@@ -924,6 +925,16 @@ static int exec_set_pointers(Exec* E, const void* const* dev_inputs, void* const
   return CTN_OK;
 }
 
+// A new set of operands starts in the caller's mode: an executor that switched itself to eager rescaling for one
+// extreme input (exec_fetch_checked) tries the lazy form - hipGraph replay, grouped leaf steps, no k_renorm passes -
+// again on the next one, and after kEagerSticky such switches in a row it stays eager (a caller who keeps sending
+// extreme operands should not pay two contractions each time).
+constexpr int kEagerSticky = 3;
+static void exec_new_run(Exec* E) {
+  if (E->eager_forced) { E->eager_rescale = true; return; }
+  if (E->eager_rescale && E->eager_streak < kEagerSticky) E->eager_rescale = false;
+}
+
 }  // namespace ctn
 
 // ---------------------------------------------------------------------------
@@ -1204,6 +1215,7 @@ int ctn_exec_enqueue(ctn_exec* exec, const void* const* dev_inputs, void* const*
   HIPCHECK(dg.err);
   int rc = exec_set_pointers(E, dev_inputs, dev_outs);
   if (rc != CTN_OK) return rc;
+  exec_new_run(E);
   return exec_launch_all(E);
 }
 
@@ -1229,13 +1241,15 @@ int ctn_exec_synchronize(ctn_exec* exec) {
 // scale registers the run has just produced, so the test costs nothing on the device: non-finite anywhere, an
 // accumulator magnitude beyond 2^+-100 (fp32; 2^+-900 fp64), or an all-zero output behind operand scales that
 // could have flushed it.
-static bool exec_scales_suspect(const Exec* E) {
+static bool exec_scales_suspect(const Exec* E, const double* resc = nullptr, int replicas = -1) {
   const Plan& P = *E->plan;
   if (!P.stabilize || (P.chain && E->d_chain)) return false;   // the chain walker divides operands on load
   const double hi = std::ldexp(1.0, P.dtype == CTN_F64 ? 900 : 100), lo = 1.0 / hi;
   const double zhi = std::ldexp(1.0, P.dtype == CTN_F64 ? 500 : 60), zlo = 1.0 / zhi;
-  for (int r = 0; r < E->R; ++r) {
-    const double* rs = E->h_resc.data() + (size_t)r * P.n_steps;
+  if (!resc) resc = E->h_resc.data();
+  if (replicas < 0) replicas = E->R;
+  for (int r = 0; r < replicas; ++r) {
+    const double* rs = resc + (size_t)r * P.n_steps;
     for (int s = 0; s < P.n_steps; ++s) {
       const Step& st = P.steps[s];
       auto scale_of = [&](int id) {
@@ -1266,9 +1280,11 @@ static int exec_fetch_checked(Exec* E, double* log_scale) {
       HIPCHECK(hipMemcpyAsync(log_scale, E->d_log, (size_t)E->R * 8, hipMemcpyDeviceToHost, E->stream));
     HIPCHECK(hipMemcpyAsync(E->h_resc.data(), E->d_resc, E->h_resc.size() * 8, hipMemcpyDeviceToHost, E->stream));
     HIPCHECK(hipStreamSynchronize(E->stream));
-    if (E->eager_rescale || !E->ptrs_valid || !exec_scales_suspect(E)) break;
+    if (E->eager_rescale || !E->ptrs_valid) break;
+    if (!exec_scales_suspect(E)) { E->eager_streak = 0; break; }
     E->eager_rescale = true;
     E->eager_reruns++;
+    E->eager_streak++;
     const int rc = exec_launch_all(E);
     if (rc != CTN_OK) return rc;
   }
@@ -1350,6 +1366,7 @@ int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space, vo
   }
   int rc = exec_set_pointers(E, din.data(), dout.data());
   if (rc != CTN_OK) return rc;
+  exec_new_run(E);
   rc = exec_launch_all(E);
   if (rc != CTN_OK) return rc;
   rc = exec_fetch_checked(E, log_scale);      // may repeat the contraction in eager-rescale mode
@@ -1362,6 +1379,42 @@ int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space, vo
     }
     HIPCHECK(hipStreamSynchronize(E->stream));
   }
+  return CTN_OK;
+}
+
+int ctn_exec_snapshot_scales(ctn_exec* exec, double* dev_log_dst, int n, double* host_rescales) {
+  if (!exec || n < 0 || n > exec->e.R) { g_err = "invalid argument to ctn_exec_snapshot_scales"; return CTN_INVALID_ARG; }
+  Exec* E = &exec->e;
+  DeviceGuard dg(E->device);
+  HIPCHECK(dg.err);
+  if (dev_log_dst && n)
+    HIPCHECK(hipMemcpyAsync(dev_log_dst, E->d_log, (size_t)n * 8, hipMemcpyDeviceToDevice, E->stream));
+  if (host_rescales && n)
+    HIPCHECK(hipMemcpyAsync(host_rescales, E->d_resc, (size_t)n * E->plan->n_steps * 8, hipMemcpyDeviceToHost, E->stream));
+  return CTN_OK;
+}
+
+int ctn_exec_scales_suspect(const ctn_exec* exec, const double* host_rescales, int replicas) {
+  if (!exec || !host_rescales || replicas < 0) { g_err = "invalid argument to ctn_exec_scales_suspect"; return CTN_INVALID_ARG; }
+  if (exec->e.eager_rescale) return 0;     // an eager run normalises every intermediate: nothing to suspect
+  return exec_scales_suspect(&exec->e, host_rescales, replicas) ? 1 : 0;
+}
+
+int ctn_exec_combine_split(ctn_exec* exec, int t_dtype, const void* t, int64_t t_stride, const double* c,
+                           int64_t c_stride, int n, int64_t numel, double* out_packed) {
+  if (!exec || !t || !c || !out_packed || n < 1 || numel < 1) { g_err = "invalid argument to ctn_exec_combine_split"; return CTN_INVALID_ARG; }
+  if (n > kCombineMaxParts) { g_err = "ctn_exec_combine_split: more than 4096 parts"; return CTN_UNSUPPORTED; }
+  if (t_dtype != CTN_F32 && t_dtype != CTN_F64) { g_err = "ctn_exec_combine_split: dtype must be f32 or f64"; return CTN_UNSUPPORTED; }
+  Exec* E = &exec->e;
+  DeviceGuard dg(E->device);
+  HIPCHECK(dg.err);
+  if (t_dtype == CTN_F32)
+    hipLaunchKernelGGL(k_combine_split<float>, dim3(1), dim3(256), 0, E->stream, (const float*)t, t_stride, c, c_stride, n,
+                       numel, E->plan->min_norm, out_packed);
+  else
+    hipLaunchKernelGGL(k_combine_split<double>, dim3(1), dim3(256), 0, E->stream, (const double*)t, t_stride, c, c_stride, n,
+                       numel, E->plan->min_norm, out_packed);
+  HIPCHECK(hipGetLastError());
   return CTN_OK;
 }
 

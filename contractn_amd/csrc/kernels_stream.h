@@ -483,6 +483,66 @@ __global__ __launch_bounds__(256) void k_renorm(void* const* __restrict__ ptrs, 
 }
 
 // ---------------------------------------------------------------------------
+// k_combine_split: sum of n tensors given in split format, without leaving it - the join of index slices
+//  and of the ranks' partial results after the one all_gather:
+//     sum_i T_i e^{c_i} = e^{c*} sum_i T_i e^{c_i - c*},  c* = max c_i over the parts that are not exact zeros,
+// re-stabilised exactly like a contraction step (reference einsum.py:89-107: norm = sum|T|, rescale = norm / numel,
+// applied iff norm > min_norm).  Part i is t + i * t_stride (numel elements of TIN), its scale c[i * c_stride];
+// the result is PACKED: out[0 .. numel) = T_hat as doubles, out[numel] = c - the buffer that crosses the links.
+// One workgroup (the payloads are small: a closed network's amplitude, a few thousand elements at most - larger
+// open results take the reduce-scatter route of dist.SlicedContraction.run_device); every sum runs in a fixed
+// order, so the result is bit-reproducible.  No part live: T_hat = 0, c = 0.
+// ---------------------------------------------------------------------------
+constexpr int kCombineMaxParts = 4096;
+template <typename TIN>
+__global__ __launch_bounds__(256) void k_combine_split(const TIN* __restrict__ t, int64_t t_stride,
+                                                       const double* __restrict__ c, int64_t c_stride, int n,
+                                                       int64_t numel, double min_norm, double* __restrict__ out) {
+  __shared__ double red[4];
+  __shared__ double w[kCombineMaxParts];     // e^{c_i - c*}, 0 for an exact-zero part
+  __shared__ double cmax[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // liveness (any element != 0) and the largest scale among the live parts: one wave per part, lanes along it
+  double best = -INFINITY;
+  for (int i = wv; i < n; i += 4) {
+    const TIN* __restrict__ p = t + (size_t)i * t_stride;
+    bool nz = false;
+    for (int64_t j = lane; j < numel && !nz; j += 64) nz = p[j] != (TIN)0;
+    const bool live = __ballot(nz) != 0ull;
+    const double ci = c[(size_t)i * c_stride];
+    if (lane == 0) w[i] = live ? ci : -INFINITY;
+    if (live) best = fmax(best, ci);
+  }
+  if (lane == 0) cmax[wv] = best;
+  __syncthreads();
+  const double c_star = fmax(fmax(cmax[0], cmax[1]), fmax(cmax[2], cmax[3]));
+  if (c_star == -INFINITY) {               // every part is an exact zero
+    for (int64_t j = threadIdx.x; j <= numel; j += 256) out[j] = 0.0;
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += 256) w[i] = w[i] == -INFINITY ? 0.0 : exp(w[i] - c_star);
+  __syncthreads();
+  double absv = 0.0;
+  for (int64_t j = threadIdx.x; j < numel; j += 256) {
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double wi = w[i];
+      if (wi != 0.0) acc += (double)t[(size_t)i * t_stride + j] * wi;
+    }
+    out[j] = acc;
+    absv += fabs(acc);
+  }
+  const double norm = block_sum(absv, red);
+  double c_out = c_star;
+  if (norm > min_norm) {
+    const double rescale = norm / (double)numel;
+    for (int64_t j = threadIdx.x; j < numel; j += 256) out[j] = out[j] / rescale;   // own elements: no barrier needed
+    c_out = c_star + log(rescale);
+  }
+  if (threadIdx.x == 0) out[numel] = c_out;
+}
+
+// ---------------------------------------------------------------------------
 // K-chain: persistent small-tensor DAG walker.  One workgroup per replica executes EVERY step of
 // the plan in order (reference loop einsum.py:341-391) - no per-step launch, rescale factors of
 // all produced tensors kept in LDS.  Same arithmetic as k_element (operands divided by their

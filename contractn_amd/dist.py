@@ -25,6 +25,7 @@ in the CPU tests).  The per-slice compute goes through ``contract`` (HIP engine)
 unless a different ``contract_fn`` is injected (the CPU tests inject the oracle).
 """
 import itertools
+import os
 
 import numpy as np
 
@@ -374,6 +375,11 @@ def contract_batch_sharded(einstr, operands, label, optimize="auto", contract_fn
     distributed = dist.is_available() and dist.is_initialized()
     rank = (dist.get_rank(group) if distributed else 0) if rank is None else rank
     world = (dist.get_world_size(group) if distributed else 1) if world is None else world
+    # (checked on EVERY rank before anything is contracted: a rank with an empty chunk must not raise alone while
+    # the others wait for it in the all_gather)
+    _sizes = paths.parse_einsum_input(einstr, [tuple(o.shape) for o in operands])[2]
+    if label in _sizes and _sizes[label] < world:
+        raise ValueError(f"batch label '{label}' has extent {_sizes[label]} < {world} ranks: some rank would get no part")
     mine, lo, hi, axis = shard_batch_label(einstr, operands, label, rank, world)
     mine = [np.ascontiguousarray(o) for o in mine]
     t_loc, c_loc = contract_fn(einstr, *mine, optimize=optimize, split_format=True)
@@ -792,6 +798,7 @@ class SlicedContraction:
             # zero fills); the executor runs on its own non-blocking stream, which does not order against it
             torch.cuda.current_stream(dev).synchronize()
         self.last_slices = None   # (T_hat [n_local, ...], log_scale [n_local]) of the last local_result()
+        self._join = None         # device / pinned buffers of run_small, allocated on first use
 
     def local_result(self):
         """Run this rank's slices group by group and combine them (split format); an exact zero
@@ -809,16 +816,89 @@ class SlicedContraction:
     def run(self, group=None):
         """Contract all slices of this rank and join the ranks' partial results.
 
-        A small result (a closed network's amplitude, a few thousand elements): ONE ``all_gather`` of the packed
-        ``(T_hat, c)`` + a local combine on the host - latency-bound, no ring.  A large open result stays on the
-        device (:meth:`run_device`): reduce-scatter + all-gather over the links, SURVEY.md 8e."""
+        A small result (a closed network's amplitude, a few thousand elements) is joined ON THE DEVICE
+        (:meth:`run_small`): the slices' ``(T_hat_s, c_s)`` never leave it, one combine kernel, ONE ``all_gather``
+        of the packed ``(T_hat, c)`` - latency-bound, no ring - one more combine, one copy to the host.  A large
+        open result takes :meth:`run_device`: reduce-scatter + all-gather over the links, SURVEY.md 8e."""
         if int(np.prod(self.out_shape)) >= DEVICE_JOIN_MIN_NUMEL:
             t, c = self.run_device(group=group)
             return t.cpu().numpy(), np.asarray(c, dtype=np.float64)
-        t_loc, c_loc = self.local_result()
-        if self.world == 1:
-            return t_loc, c_loc
-        return all_gather_combine(t_loc, c_loc, group=group, world=self.world, device=self.device)
+        if self.n_total < self.world or os.environ.get("CTN_HOST_JOIN") == "1":
+            # more ranks than slices (some rank has no executor to run the combine on), or the development switch:
+            # the host join - every rank must take the same route through the collective
+            t_loc, c_loc = self.local_result()
+            if self.world == 1:
+                return t_loc, c_loc
+            return all_gather_combine(t_loc, c_loc, group=group, world=self.world, device=self.device)
+        return self.run_small(group=group)
+
+    # -- small results: the join stays on the device -------------------------------------------------------------
+    def _join_buffers(self):
+        import torch
+
+        if self._join is None:
+            dev = torch.device("cuda", self.device)
+            numel = max(1, int(np.prod(self.out_shape)))
+            n_steps = self.bc.plan.n_steps
+            self._join = {
+                "numel": numel,
+                "c": torch.zeros(len(self.my_slices), dtype=torch.float64, device=dev),
+                "packed": torch.zeros(numel + 1, dtype=torch.float64, device=dev),
+                "gathered": torch.zeros(self.world * (numel + 1), dtype=torch.float64, device=dev),
+                "final": torch.zeros(numel + 1, dtype=torch.float64, device=dev),
+                # per-step rescale factors of every group of slices, brought over asynchronously: the range check
+                # of the lazy rescale (ctn_exec_scales_suspect) costs no extra wait
+                "resc": [torch.empty(max(n, 1) * n_steps, dtype=torch.float64).pin_memory() for _c0, n, _l in self._chunks],
+            }
+            torch.cuda.current_stream(dev).synchronize()     # the zero fills ran on torch's stream
+        return self._join
+
+    def run_small(self, group=None):
+        """The sliced contraction with a device-resident join; returns ``(T_hat [numpy], c)`` on every rank.
+
+        Per rank: the groups of slices are enqueued back to back; after each one the log-scale registers of its
+        slices are copied next to the others' ON the device (and the per-step rescale factors to pinned host memory,
+        asynchronously); `k_combine_split` then forms this rank's ``(T_hat_g, c_g) = sum_s T_hat_s e^{c_s}`` in one
+        launch, packed as ``numel + 1`` doubles.  Across ranks: ONE ``all_gather`` of that packed buffer (16 bytes
+        for a closed network), the same kernel over the ``world`` parts, ONE copy to the host."""
+        import torch
+        import torch.distributed as dist
+
+        J = self._join_buffers()
+        ex, numel = self.bc.executor, J["numel"]
+        dev = torch.device("cuda", self.device)
+        with ex.lock:
+            for k, (c0, n, launch) in enumerate(self._chunks):
+                launch()
+                ex.snapshot_scales(J["c"].data_ptr() + 8 * c0, n, J["resc"][k].data_ptr())
+            ex.combine_split(self.out.data_ptr(), numel, J["c"].data_ptr(), 1, len(self.my_slices), numel,
+                             J["packed"].data_ptr())
+            ex.synchronize()
+            if any(ex.scales_suspect(J["resc"][k].data_ptr(), n) for k, (_c0, n, _l) in enumerate(self._chunks)):
+                # a lazily rescaled product left the dtype's range: this rank's part again through the checked path
+                # (ctn_exec_fetch repeats such a group with eager rescaling)
+                t_loc, c_loc = self.local_result()
+                host = np.concatenate([np.asarray(t_loc, dtype=np.float64).ravel(), [float(c_loc)]])
+                J["packed"].copy_(torch.from_numpy(host))
+                torch.cuda.current_stream(dev).synchronize()
+            result = J["packed"]
+            if self.world > 1:
+                if dist.get_backend(group) == "nccl":
+                    dist.all_gather_into_tensor(J["gathered"], J["packed"], group=group)      # THE join
+                else:   # gloo (CPU tests, one-GPU rehearsals): the same buffer crosses through the host
+                    send = J["packed"].cpu()
+                    recv = [torch.empty_like(send) for _ in range(self.world)]
+                    dist.all_gather(recv, send, group=group)
+                    J["gathered"].copy_(torch.cat(recv))
+                torch.cuda.current_stream(dev).synchronize()
+                g = J["gathered"].data_ptr()
+                ex.combine_split(g, numel + 1, g + 8 * numel, numel + 1, self.world, numel, J["final"].data_ptr(),
+                                 dtype=np.float64)
+                ex.synchronize()
+                result = J["final"]
+            host = result.cpu().numpy()
+        t = host[:numel].reshape(self.out_shape).astype(self.np_dtype)
+        return t, np.asarray(host[numel], dtype=np.float64)
 
     # -- large open outputs: everything stays on the device -------------------------------------------------------
     def local_result_device(self):
@@ -836,7 +916,6 @@ class SlicedContraction:
         if self.bc is None:
             return torch.zeros(self.out_shape, device=dev, dtype=self.out_dtype_torch()), None
         logs = np.zeros(len(self.my_slices))
-        live = np.zeros(len(self.my_slices), dtype=bool)
         for c0, n, launch in self._chunks:
             launch()
             _dev_log, resc = self.bc.executor.fetch()            # waits for the group
@@ -844,7 +923,10 @@ class SlicedContraction:
 
             for r in range(n):
                 logs[c0 + r] = accumulate_log_scale(resc[r], self.np_dtype)
-                live[c0 + r] = resc[r][-1] != 0.0                # the final tensor was rescaled: not an exact zero
+        # a slice counts unless its result is an EXACT zero - the rule of `combine_split`; a tiny result that was
+        # never rescaled (sum |T| <= 1e-7) still contributes, weighted like the others
+        flat = self.out.reshape(len(self.my_slices), -1)
+        live = (flat != 0).any(dim=1).cpu().numpy()
         if not live.any():
             return torch.zeros(self.out_shape, device=dev, dtype=self.out_dtype_torch()), None
         c_star = float(np.max(logs[live]))

@@ -92,41 +92,84 @@ def _contract_path(einstr, operand_shapes, **kwargs):
     return paths.contraction_list(einstr, operand_shapes, **kwargs)
 
 
-def lower_contraction_list(n_operands, contract_list):
+def lower_contraction_list(n_operands, contract_list, shapes=None):
     """opt_einsum-style shrinking positions -> SSA steps with integer labels.
 
     Returns ``(in_labels, steps)``; ``steps[k] = (lhs_id, rhs_id | -1, out_labels)``,
     inputs are ids ``0..n-1`` and step ``k`` defines id ``n+k``.  The operand popped
     from the higher position is the left one (reference einsum.py:344).
+
+    A step on more than two operands (``optimize=False`` - ONE einsum over everything - or an explicit path with
+    n-ary steps; the reference hands any step to ``_einsum``, einsum.py:382-384) is lowered to a chain of pairwise
+    steps in the order the greedy finder picks for that sub-network (``shapes`` are needed for that; without them:
+    left to right), every intermediate keeping the labels the rest of the step or its result still need.  The
+    result ``(T_hat, c)`` is that of the single einsum up to rounding: ``c = ln mean|T|`` whatever the order
+    (SURVEY.md App. A); the native plan then simply has more steps than the contraction list.
     """
     live = list(range(n_operands))
-    terms = {}
+    term_of = {}
+    # first pass: the term of every network input (needed for the extents before any n-ary step is ordered)
+    probe = list(range(n_operands))
+    fake = n_operands
+    for num, (inds, _idx_rm, step_str, _rest, _flag) in enumerate(contract_list):
+        ids = [probe.pop(p) for p in inds]
+        parts = step_str.split("->")[0].split(",")
+        if len(parts) != len(ids) or not ids:
+            raise ValueError(f"step {num}: {len(parts)} terms for {len(ids)} operands")
+        for tid, term in zip(ids, parts):
+            if tid < n_operands:
+                term_of.setdefault(tid, term)
+        probe.append(fake)
+        fake += 1
+    sizes = {}
+    if shapes is not None:
+        for i, term in term_of.items():
+            for c, d in zip(term, shapes[i]):
+                sizes[c] = int(d)
     steps = []
+
+    def emit(lhs, rhs, out):
+        steps.append((lhs, rhs, tuple(ord(c) for c in out)))
+        return n_operands + len(steps) - 1
+
     for num, (inds, _idx_rm, step_str, _rest, _flag) in enumerate(contract_list):
         ids = [live.pop(p) for p in inds]
         lhs, out = step_str.split("->")
         parts = lhs.split(",")
-        if len(parts) != len(ids) or len(ids) not in (1, 2):
-            raise NotImplementedError(
-                f"step {num}: only unary and pairwise contraction steps are supported"
-            )
-        for tid, term in zip(ids, parts):
-            if tid < n_operands:
-                terms.setdefault(tid, term)
-        new_id = n_operands + num
-        live.append(new_id)
-        steps.append((ids[0], ids[1] if len(ids) == 2 else -1, tuple(ord(c) for c in out)))
+        if len(ids) <= 2:
+            live.append(emit(ids[0], ids[1] if len(ids) == 2 else -1, out))
+            continue
+        # n-ary step: pairwise chain over (id, term) items
+        items = list(zip(ids, parts))
+        if sizes and all(c in sizes for t in parts for c in t):
+            order = paths.find_path(parts, out, sizes, "greedy")
+        else:
+            order = [(0, 1)] * (len(items) - 1)
+        for k, pos in enumerate(order):
+            pos = tuple(sorted(pos, reverse=True))
+            if len(pos) != 2:
+                raise NotImplementedError(f"step {num}: cannot order a {len(ids)}-operand step pairwise")
+            (ia, ta), (ib, tb) = items.pop(pos[0]), items.pop(pos[1])
+            if k == len(order) - 1:
+                res = out
+            else:
+                needed = set(out).union(*[set(t) for _i, t in items])
+                res = "".join(c for c in dict.fromkeys(ta + tb) if c in needed)
+            items.append((emit(ia, ib, res), res))
+        if len(items) != 1:
+            raise ValueError(f"step {num}: the pairwise order does not reduce its {len(ids)} operands to one")
+        live.append(items[0][0])
     if len(live) != 1:
         raise ValueError("contraction list does not reduce the operands to a single tensor")
-    missing = [i for i in range(n_operands) if i not in terms]
+    missing = [i for i in range(n_operands) if i not in term_of]
     assert not missing, f"operands {missing} never contracted"
-    in_labels = [tuple(ord(c) for c in terms[i]) for i in range(n_operands)]
+    in_labels = [tuple(ord(c) for c in term_of[i]) for i in range(n_operands)]
     return in_labels, steps
 
 
 @lru_cache(maxsize=256)
 def _native_plan_cached(contract_list, shapes, dtype_name):
-    in_labels, steps = lower_contraction_list(len(shapes), contract_list)
+    in_labels, steps = lower_contraction_list(len(shapes), contract_list, shapes)
     for lab, shp in zip(in_labels, shapes):
         if len(lab) != len(shp):
             raise ValueError(f"operand of shape {shp} does not match its {len(lab)} subscripts")
@@ -193,17 +236,22 @@ def clear_caches():
 # ---------------------------------------------------------------------------
 # scale register (host part of stabilize / destabilize)
 # ---------------------------------------------------------------------------
-def accumulate_log_scale(step_rescales, dtype):
+def accumulate_log_scale(step_rescales, dtype, register_dtype=np.float64):
     """Sum of log(rescale) over the steps, in path order, with the reference's
     NumPy semantics (reference einsum.py:104-106): ``log`` is
-    evaluated in the tensor dtype, the register is a float64 0-d array."""
+    evaluated in the tensor dtype, the register is a float64 0-d array.
+
+    ``register_dtype``: the reference's TORCH backend keeps the register in the tensor dtype - a
+    ``torch.float32`` 0-d tensor (``torch.zeros(())``, einsum.py:338) that every step adds to in fp32 - so torch
+    operands pass their dtype here: same logs, the strictly sequential adds in that precision."""
     resc = np.asarray(step_rescales, dtype=np.float64)
-    logs = np.zeros(resc.shape, dtype=np.float64)
+    reg = np.dtype(register_dtype)
+    logs = np.zeros(resc.shape, dtype=reg)
     mask = resc > 0
-    logs[mask] = np.log(resc[mask].astype(dtype)).astype(np.float64)
+    logs[mask] = np.log(resc[mask].astype(dtype)).astype(reg)
     if logs.size == 0:
-        return np.zeros(())
-    return np.asarray(np.add.accumulate(logs)[-1])  # strictly sequential adds
+        return np.zeros((), dtype=reg)
+    return np.asarray(np.add.accumulate(logs)[-1])  # strictly sequential adds, in the register's precision
 
 
 def stabilize(tensor, log_scale, backend="auto"):
@@ -302,8 +350,8 @@ def _run_torch(plan, operands, dtype):
         host = [o.detach().cpu().numpy() for o in operands]
         with ex.lock:
             outs, _dev_log, resc = ex.run_host([host])
-        log_scale = accumulate_log_scale(resc[0], dtype)
-        return torch.from_numpy(outs[0]), torch.tensor(float(log_scale), dtype=tdt)
+        log_scale = accumulate_log_scale(resc[0], dtype, register_dtype=dtype)
+        return torch.from_numpy(np.array(outs[0])), torch.tensor(float(log_scale), dtype=tdt)   # (a closed network: 0-d)
     dev = operands[0].device
     ops = [o.to(device=dev, dtype=tdt).contiguous() for o in operands]
     # views into a larger storage may start at an odd offset: vector loads need 16-byte alignment
@@ -319,7 +367,8 @@ def _run_torch(plan, operands, dtype):
     with ex.lock:
         ex.enqueue([o.data_ptr() for o in ops], [out.data_ptr()])
         _dev_log, resc = ex.fetch()
-    log_scale = accumulate_log_scale(resc[0], dtype)
+    # the torch backend's register: the tensor dtype, sequential adds in it (reference einsum.py:338; App. A)
+    log_scale = accumulate_log_scale(resc[0], dtype, register_dtype=dtype)
     return out, torch.tensor(float(log_scale), dtype=tdt, device=dev)
 
 

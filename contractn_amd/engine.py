@@ -38,6 +38,7 @@ ABI_SYMBOLS = (
     "ctn_exec_create", "ctn_exec_destroy", "ctn_exec_run", "ctn_exec_enqueue",
     "ctn_exec_fetch", "ctn_exec_synchronize", "ctn_exec_set_timing", "ctn_exec_step_ms",
     "ctn_exec_step_tile", "ctn_exec_set_rescale_mode", "ctn_exec_eager_reruns",
+    "ctn_exec_snapshot_scales", "ctn_exec_scales_suspect", "ctn_exec_combine_split",
 )
 
 
@@ -153,6 +154,9 @@ def load_library():
         "ctn_exec_step_tile": (i32, [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "ctn_exec_set_rescale_mode": (i32, [vp, i32]),
         "ctn_exec_eager_reruns": (i32, [vp]),
+        "ctn_exec_snapshot_scales": (i32, [vp, vp, i32, vp]),
+        "ctn_exec_scales_suspect": (i32, [vp, vp, i32]),
+        "ctn_exec_combine_split": (i32, [vp, i32, vp, i64, vp, i64, i32, i64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -405,6 +409,26 @@ class Executor:
     def eager_reruns(self):
         """How often a fetch found a lazily rescaled product out of range and repeated the contraction eagerly."""
         return _check(self._lib.ctn_exec_eager_reruns(self._h))
+
+    # -- device-side join of split-format partial results (include/ctn_abi.h) ------------------
+    def snapshot_scales(self, dev_log_ptr, n, host_resc_ptr=0):
+        """After an enqueue: copy the log-scale registers of its first ``n`` replicas to device address
+        ``dev_log_ptr`` and (optionally) their per-step rescale factors to pinned host address ``host_resc_ptr``,
+        asynchronously on the executor's stream."""
+        _check(self._lib.ctn_exec_snapshot_scales(self._h, C.c_void_p(dev_log_ptr or None), int(n),
+                                                  C.c_void_p(host_resc_ptr or None)))
+
+    def scales_suspect(self, host_resc_ptr, replicas):
+        """The range check of ``fetch`` on rescale factors already on the host (``replicas * n_steps`` doubles)."""
+        return bool(_check(self._lib.ctn_exec_scales_suspect(self._h, C.c_void_p(host_resc_ptr), int(replicas))))
+
+    def combine_split(self, t_ptr, t_stride, c_ptr, c_stride, n, numel, out_ptr, dtype=None):
+        """Enqueue ``out[0:numel], out[numel] = (T_hat, c)`` of ``sum_i t_i exp(c_i)`` over ``n`` parts (device
+        pointers; ``t`` of ``dtype``, default the plan's; ``c`` and ``out`` float64)."""
+        dt = self.plan.np_dtype if dtype is None else np.dtype(dtype)
+        _check(self._lib.ctn_exec_combine_split(self._h, CTN_F32 if dt == np.float32 else CTN_F64, C.c_void_p(t_ptr),
+                                                int(t_stride), C.c_void_p(c_ptr), int(c_stride), int(n), int(numel),
+                                                C.c_void_p(out_ptr)))
 
     def set_timing(self, slots):
         """Bracket every step of the next ``slots`` enqueues with HIP events (0 = off)."""

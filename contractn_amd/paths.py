@@ -179,6 +179,45 @@ def path_cost(term_sets, out, sizes, path):
     return flops, biggest
 
 
+def hoisted_cost(term_sets, out, sizes, path, slice_labels, parallel=1):
+    """Work of an index-sliced path when slice-INDEPENDENT work is done once (`dist.StagedSlicing`): a node of the
+    tree is evaluated once per joint value of the sliced labels its subtree depends on - those carried by one of its
+    leaves - not once per slice.  A label that is contracted at the root therefore slices for free, and a subtree that
+    touches no sliced label is computed a single time.  Returns ``(total multiply-adds over all evaluations, largest
+    intermediate - sliced where it carries sliced labels -, multiply-adds of one slice evaluated in full)``;
+    ``sizes`` are the UNSLICED extents.
+
+    ``parallel`` = the number of ranks the slices are meant to be dealt to: a node evaluated fewer times than that
+    cannot be shared out (every rank needs its result: the work is replicated, or the others wait), so it is
+    charged ``parallel`` evaluations - the first figure is then ``parallel`` x the modelled time of one rank, and
+    a slicing whose sliced labels sit in a corner of the network (nearly everything slice-independent: no overhead,
+    no parallelism either) stops looking free."""
+    sl = list(slice_labels)
+    sz = dict(sizes)
+    for lab in sl:
+        sz[lab] = 1
+    live = [(set(t), sum(1 << b for b, lab in enumerate(sl) if lab in t)) for t in term_sets]
+    total, biggest, one = 0, 0, 0
+    for step in path:
+        step = tuple(sorted(step))
+        if len(step) == 1:
+            continue
+        i, j = step
+        (a, da), (b, db) = live[i], live[j]
+        rest = [x for k, x in enumerate(live) if k not in (i, j)]
+        new, _ = _pair_result(a, b, [x[0] for x in rest], out)
+        times = 1
+        for bit, lab in enumerate(sl):
+            if (da | db) >> bit & 1:
+                times *= sizes[lab]
+        c = _size(a | b, sz)
+        total += c * max(times, parallel)
+        one += c
+        biggest = max(biggest, _size(new, sz))
+        live = rest + [(new, da | db)]
+    return total, biggest, one
+
+
 def path_time_model(term_sets, out, sizes, path, elem_bytes=4):
     """Rough device time of a path in microseconds, for choosing between candidate paths of similar multiply-add
     counts: per step the larger of (tile-padded multiply-adds at 60 T/s: rows to 128, columns to 64) and (operand
@@ -239,14 +278,18 @@ def _ssa_pairs_to_linear(pairs, n):
     return path
 
 
-def _dp(term_sets, out, sizes, memory_limit=None):
+def _dp(term_sets, out, sizes, memory_limit=None, dep=None, dep_mult=None):
     """Exact minimum-flop pairwise order by dynamic programming over operand subsets (the published
     algorithm behind opt_einsum's ``'dp'``: best tree of every subset from the best trees of its
     two-way splits).  Subsets are bit masks; the labels a subset keeps are those also needed outside
     it (other operands or the output), which makes hyperedges (labels shared by more than two
     operands) come out right.  Every split is considered, outer products included (they are
     sometimes the cheapest way to absorb small vectors), so the result equals the exhaustive search's.
-    O(3^n): used up to 12 operands."""
+    O(3^n): used up to 12 operands.
+
+    ``dep`` / ``dep_mult`` (index slicing with slice-independent work done once, `hoisted_cost`): ``dep[k]`` is a
+    bit mask of the sliced labels operand ``k`` depends on and ``dep_mult(bits)`` how many times a node depending on
+    ``bits`` is evaluated; a node then costs its (sliced) index space times that number."""
     n = len(term_sets)
     out_set = set(out)
     full = (1 << n) - 1
@@ -273,6 +316,7 @@ def _dp(term_sets, out, sizes, memory_limit=None):
     # an input keeps ALL its labels until its first contraction (a label nobody else needs is summed there
     # and still spans that step's iteration space)
     keep = {1 << k: set(term_sets[k]) for k in range(n)}
+    depm = {1 << k: (dep[k] if dep is not None else 0) for k in range(n)}
     for mask in range(1, full + 1):
         if mask & (mask - 1) == 0:
             continue
@@ -280,10 +324,12 @@ def _dp(term_sets, out, sizes, memory_limit=None):
         sub = (mask - 1) & mask
         cand = None
         over = memory_limit is not None and mask != full and _size(kept(mask), sizes) > memory_limit
+        depm[mask] = depm[lowest] | depm[mask ^ lowest]
+        times = dep_mult(depm[mask]) if dep is not None else 1
         while sub:
             if sub & lowest:   # canonical: the left part holds the subset's lowest operand
                 right = mask ^ sub
-                cost = best[sub][0] + best[right][0] + _size(keep[sub] | keep[right], sizes)
+                cost = best[sub][0] + best[right][0] + _size(keep[sub] | keep[right], sizes) * times
                 if over:
                     cost += 1 << 200    # still possible, but only if nothing else fits
                 if cand is None or cost < cand[0]:
@@ -436,7 +482,8 @@ def _best_cluster_sweep(term_sets, out, sizes, bound=None):
     return None if best is None else best[1]
 
 
-def _reconfigure(term_sets, out, sizes, path, max_leaves=8, rounds=8, memory_limit=None):
+def _reconfigure(term_sets, out, sizes, path, max_leaves=8, rounds=8, memory_limit=None, slice_labels=None,
+                 parallel=1):
     """Subtree reconfiguration of a pairwise contraction tree (the refinement step of hyper-optimised
     path finders): for every internal node, cut out the subtree spanned by up to ``max_leaves`` of its
     descendants (largest intermediates expanded first), solve that small network EXACTLY with the
@@ -444,10 +491,31 @@ def _reconfigure(term_sets, out, sizes, path, max_leaves=8, rounds=8, memory_lim
     the result when it is cheaper (and, under a ``memory_limit``, does not push an intermediate of the
     subtree past both the limit and what the subtree already had).  Never worse than the input path in
     flops; returns a linear path.  8 x 8 PEPS, D = 8: 1.2e12 -> 2.2e11 multiply-adds in under a second
-    (the hand-written row sweep costs 3.2e11)."""
+    (the hand-written row sweep costs 3.2e11).
+
+    ``slice_labels`` (with ``sizes`` the UNSLICED extents): optimise the work of the index-sliced contraction with
+    slice-independent work done once (`hoisted_cost`) - a node costs its sliced index space times the number of
+    joint values of the sliced labels its subtree depends on (at least ``parallel``, see `hoisted_cost`)."""
     n = len(term_sets)
     if n < 4:
         return list(path)
+    sl = list(slice_labels or ())
+    full_sizes = sizes
+    if sl:
+        sizes = dict(sizes)
+        for lab in sl:
+            sizes[lab] = 1
+    mult_cache = {}
+
+    def dep_mult(bits):
+        if bits not in mult_cache:
+            m = 1
+            for b, lab in enumerate(sl):
+                if bits >> b & 1:
+                    m *= full_sizes[lab]
+            mult_cache[bits] = max(m, parallel)
+        return mult_cache[bits]
+
     out_set = set(out)
     total = {}
     for t in term_sets:
@@ -456,6 +524,7 @@ def _reconfigure(term_sets, out, sizes, path, max_leaves=8, rounds=8, memory_lim
 
     # tree as dicts keyed by node id: leaves 0..n-1, internal nodes get fresh ids
     kids, count = {}, {i: {lab: 1 for lab in set(t)} for i, t in enumerate(term_sets)}
+    depb = {i: sum(1 << b for b, lab in enumerate(sl) if lab in t) for i, t in enumerate(term_sets)}
     live, nxt = list(range(n)), n
     for step in path:
         step = tuple(sorted(step))
@@ -468,6 +537,7 @@ def _reconfigure(term_sets, out, sizes, path, max_leaves=8, rounds=8, memory_lim
         for lab, v in count[b].items():
             c[lab] = c.get(lab, 0) + v
         count[nxt] = c
+        depb[nxt] = depb[a] | depb[b]
         nxt += 1
     root = live[0]
 
@@ -485,7 +555,7 @@ def _reconfigure(term_sets, out, sizes, path, max_leaves=8, rounds=8, memory_lim
 
     def node_cost(v):
         a, b = kids[v]
-        return _size(L(a) | L(b), sizes)
+        return _size(L(a) | L(b), sizes) * (dep_mult(depb[v]) if sl else 1)
 
     for _ in range(rounds):
         improved = False
@@ -512,8 +582,21 @@ def _reconfigure(term_sets, out, sizes, path, max_leaves=8, rounds=8, memory_lim
                 continue
             old_cost = sum(node_cost(x) for x in inner)
             sub_sets = [L(x) for x in frontier]
-            sub_path = _dp(sub_sets, L(v), sizes, memory_limit=memory_limit)
-            new_cost, new_big = path_cost(sub_sets, L(v), sizes, sub_path)
+            if sl:
+                sub_dep = [depb[x] for x in frontier]
+                sub_path = _dp(sub_sets, L(v), sizes, memory_limit=memory_limit, dep=sub_dep, dep_mult=dep_mult)
+                _plain, new_big = path_cost(sub_sets, L(v), sizes, sub_path)
+                new_cost, cur_d = 0, list(zip(sub_sets, sub_dep))
+                for st in sub_path:          # the same objective, read off the path
+                    i_, j_ = sorted(st)
+                    (a_, da_), (b_, db_) = cur_d[i_], cur_d[j_]
+                    rest_ = [x for q, x in enumerate(cur_d) if q not in (i_, j_)]
+                    kept_, _ = _pair_result(a_, b_, [x[0] for x in rest_], L(v))
+                    new_cost += _size(a_ | b_, sizes) * dep_mult(da_ | db_)
+                    cur_d = rest_ + [(kept_, da_ | db_)]
+            else:
+                sub_path = _dp(sub_sets, L(v), sizes, memory_limit=memory_limit)
+                new_cost, new_big = path_cost(sub_sets, L(v), sizes, sub_path)
             if new_cost >= old_cost:
                 continue
             if memory_limit is not None and new_big > max(memory_limit, max(_size(L(x), sizes) for x in inner)):
@@ -536,6 +619,7 @@ def _reconfigure(term_sets, out, sizes, path, max_leaves=8, rounds=8, memory_lim
                     for lab, val in count[b].items():
                         c[lab] = c.get(lab, 0) + val
                     count[nid] = c
+                    depb[nid] = depb[a] | depb[b]
                 kids[nid] = (a, b)
                 cur = [x for q, x in enumerate(cur) if q not in (i, j)] + [nid]
         if not improved:
@@ -576,7 +660,9 @@ def find_path(terms, out, sizes, optimize, memory_limit=None):
     sets = [set(t) for t in terms]
     name = "auto" if optimize in (True, None) else optimize
     if name is False:
-        raise ValueError("optimize=False (single n-ary einsum) is not supported by the HIP engine")
+        # opt_einsum: no optimisation = ONE step over every operand (a single einsum); the engine orders it
+        # pairwise when the contraction list is lowered (einsum.lower_contraction_list)
+        return [tuple(range(n))]
     if name in ("auto", "auto-hq"):
         # few operands: exact; up to 12: exact by subset DP; beyond: see the last branch
         if n < 5:

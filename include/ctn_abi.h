@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CTN_ABI_VERSION 2
+#define CTN_ABI_VERSION 3
 
 typedef enum {
   CTN_OK = 0,
@@ -181,6 +181,27 @@ int ctn_exec_synchronize(ctn_exec* exec);
  */
 int ctn_exec_set_rescale_mode(ctn_exec* exec, int mode);
 int ctn_exec_eager_reruns(const ctn_exec* exec);
+
+/*
+ * Device-side join of partial results in split format (the index slices of one network run as the
+ * replicas of one executor, each producing (T_hat_s, c_s); ranks exchange ONE packed buffer).  The reference has
+ * no counterpart (single process); the arithmetic is that of its stabilize(), einsum.py:89-107, applied to a sum.
+ *
+ * ctn_exec_snapshot_scales: after an enqueue, copy the log-scale registers of its first `n` replicas to
+ *   `dev_log_dst` (device, n doubles) and - optionally - their per-step rescale factors to `host_rescales`
+ *   (pinned host memory, n * n_steps doubles), both asynchronously on the executor's stream: no host wait.
+ * ctn_exec_scales_suspect: the range check ctn_exec_fetch applies (see ctn_exec_set_rescale_mode), on rescale
+ *   factors the caller has brought to the host itself; 1 = a lazily rescaled product may have left the dtype's
+ *   range (repeat that enqueue and ctn_exec_fetch it), 0 = fine, negative = ctn_status.
+ * ctn_exec_combine_split: on the executor's stream, out_packed[0 .. numel) = T_hat (as doubles) and
+ *   out_packed[numel] = c of  sum_i t_i e^{c_i}  over n parts; part i is t + i * t_stride elements of `t_dtype`,
+ *   its scale c[i * c_stride]; exact zeros are left out of the maximum, the sum is re-stabilised (mean |T_hat| = 1
+ *   when sum |T| > min_norm of the plan), bit-reproducible.  n <= 4096; all pointers are device pointers.
+ */
+int ctn_exec_snapshot_scales(ctn_exec* exec, double* dev_log_dst, int n, double* host_rescales);
+int ctn_exec_scales_suspect(const ctn_exec* exec, const double* host_rescales, int replicas);
+int ctn_exec_combine_split(ctn_exec* exec, int t_dtype, const void* t, int64_t t_stride, const double* c,
+                           int64_t c_stride, int n, int64_t numel, double* out_packed);
 
 /*
  * Workgroup tile (rows, columns) of the MFMA kernel that the LAST enqueue launched for `step`

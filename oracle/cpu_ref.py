@@ -39,6 +39,21 @@ def stabilize(tensor, log_scale):
     return tensor, log_scale
 
 
+def stabilize_torch(tensor, log_scale):
+    """reference einsum.py:89-107 as its TORCH backend evaluates it (einsum.py:9-21, register from
+    ``torch.zeros(())`` at :338): every scalar - norm, rescale, log, the register itself - has the tensor's dtype,
+    so for float32 tensors the register is accumulated in fp32 (last row).  Restated on NumPy
+    arrays of that dtype (a float64 tensor promotes the fp32 zero on the first add: register float64)."""
+    dt = tensor.dtype.type
+    norm = dt(np.sum(np.abs(tensor)))
+    numel = reduce(operator.mul, tensor.shape, 1)
+    rescale = dt(norm / dt(numel))
+    if norm > MIN_NORM:
+        tensor = tensor / rescale
+        log_scale = dt(dt(log_scale) + np.log(rescale))
+    return tensor, log_scale
+
+
 def destabilize(tensor, log_scale):
     """reference einsum.py:110-114."""
     return tensor * np.exp(log_scale)
@@ -59,7 +74,7 @@ def _einsum_remapped(step_str, *ops):
     return np.einsum("".join(out), *ops)
 
 
-def core_contract(operands, contract_list, record=False):
+def core_contract(operands, contract_list, record=False, torch_register=False):
     """reference einsum.py:326-393: the stabilised pairwise loop.
 
     ``contract_list[k] = (positions_desc, idx_removed, "L,R->O", _, blas_flag)``.
@@ -67,7 +82,7 @@ def core_contract(operands, contract_list, record=False):
     holds every step's rescale factor (0.0 where a step was not rescaled).
     """
     operands = list(operands)
-    log_scale = np.zeros(())  # einsum.py:338
+    log_scale = np.float32(0) if torch_register else np.zeros(())  # einsum.py:338 (torch: torch.zeros(()) is fp32)
     rescales = []
     for inds, idx_rm, step_str, _rest, blas_flag in contract_list:
         tmp = [operands.pop(x) for x in inds]  # einsum.py:344
@@ -88,7 +103,7 @@ def core_contract(operands, contract_list, record=False):
         if record:
             norm = np.sum(np.abs(new_view))
             rescales.append(float(norm / new_view.size) if norm > MIN_NORM else 0.0)
-        new_view, log_scale = stabilize(new_view, log_scale)  # einsum.py:387
+        new_view, log_scale = (stabilize_torch if torch_register else stabilize)(new_view, log_scale)  # einsum.py:387
         operands.append(new_view)  # einsum.py:390
     return operands[0], log_scale, rescales
 
@@ -140,13 +155,14 @@ def left_to_right_path(n):
     return path if n > 1 else [(0,)]
 
 
-def contract(einstr, *operands, path=None, split_format=False):
-    """reference einsum.py:190-310 for NumPy operands and an explicit path."""
+def contract(einstr, *operands, path=None, split_format=False, torch_register=False):
+    """reference einsum.py:190-310 for NumPy operands and an explicit path (``torch_register``: the register
+    arithmetic of the reference's torch backend, see `stabilize_torch`)."""
     shapes = [np.shape(o) for o in operands]
     if path is None:
         path = left_to_right_path(len(operands))
     clist = contraction_list(einstr, shapes, path)
-    result, log_scale, _ = core_contract([np.asarray(o) for o in operands], clist)
+    result, log_scale, _ = core_contract([np.asarray(o) for o in operands], clist, torch_register=torch_register)
     if split_format:
         return result, log_scale
     with np.errstate(over="ignore"):

@@ -71,6 +71,37 @@ def save(name, tn, path, inputs=(), note=""):
           f"log_scale={float(log_scale):+.12g}")
 
 
+def save_torch(name, tn, path, note=""):
+    """The same network through the reference's TORCH backend (einsum.py:9-21: CPU tensors here): the register is a
+    ``torch.float32`` 0-d tensor accumulated in fp32 (``torch.zeros(())``, einsum.py:338; SURVEY.md App. A last row),
+    which the NumPy fixtures cannot pin.  Operands: the TN's tensors as float32."""
+    if ONLY and name not in ONLY:
+        return
+    import torch
+    from contractn import contract as ref_contract
+    from contractn.einsum import make_arg_packer
+
+    operands = [np.asarray(o, dtype=np.float32) for o in make_arg_packer(tn)(tn.params, ())]
+    t_ops = [torch.from_numpy(o) for o in operands]
+    t_hat, log_scale = ref_contract(tn.einsum_str, *t_ops, optimize=path, split_format=True)
+    plain = ref_contract(tn.einsum_str, *t_ops, optimize=path, split_format=False)
+    assert log_scale.dtype == torch.float32 and t_hat.dtype == torch.float32
+    data = {
+        "einsum_str": np.array(tn.einsum_str),
+        "path": np.array([list(p) + [-1] * (2 - len(p)) for p in path], dtype=np.int64),
+        "n_operands": np.array(len(operands)),
+        "t_hat": t_hat.numpy(),
+        "log_scale": np.asarray(log_scale.numpy(), dtype=np.float32),
+        "log_scale_hex": np.array(float(log_scale).hex()),
+        "plain": plain.numpy(),
+        "note": np.array(note),
+    }
+    for i, op in enumerate(operands):
+        data[f"op{i}"] = op
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
+    print(f"{name:28s} torch fp32 register log_scale={float(log_scale):+.9g} ({float(log_scale).hex()})")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
 
@@ -92,6 +123,8 @@ def main():
         prev = mat
     save("readme_chain1000", tn, tuple(nets_left_to_right(1001)),
          note="README.md:62-77; split -> ([1,1,1], 1098.61228867), plain -> inf")
+    save_torch("readme_chain1000_torch_f32", tn, tuple(nets_left_to_right(1001)),
+               note="README.md:62-77 on the torch backend: 1000 x log(3) added up in fp32")
 
     # -- random chain (config 2 random variant)
     rng = np.random.default_rng(2)
@@ -109,6 +142,7 @@ def main():
         save(f"mps_overlap_6x8x3_{tag}", tn, ssa_to_linear(ssa, 12), note="zipper path")
     tn, ssa = nets.mps_overlap(TN, 5, 64, 4, dtype=np.float32, seed=3)
     save("mps_overlap_5x64x4_f32", tn, ssa_to_linear(ssa, 10), note="zipper path; MFMA-sized steps")
+    save_torch("mps_overlap_5x64x4_torch_f32", tn, ssa_to_linear(ssa, 10), note="zipper path, torch backend")
     tn, ssa = nets.mps_overlap(TN, 4, 48, 4, dtype=np.float64, seed=4)
     save("mps_overlap_4x48x4_f64", tn, ssa_to_linear(ssa, 8), note="zipper path")
 

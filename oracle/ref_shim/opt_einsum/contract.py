@@ -17,10 +17,16 @@ def parse_backend(arrays, backend):
 
 
 def _tensordot(x, y, axes, backend="numpy"):
+    if backend == "torch":      # dispatch only (opt_einsum/backends/torch.py does the same): the arithmetic is torch's
+        import torch
+
+        return torch.tensordot(x, y, dims=axes)
     return np.tensordot(x, y, axes=axes)
 
 
 def _transpose(x, axes, backend="numpy"):
+    if backend == "torch":
+        return x.permute(*axes)
     return np.transpose(x, axes)
 
 
@@ -33,6 +39,10 @@ def _einsum(*operands, backend="numpy", **kwargs):
         else:
             table.setdefault(ch, _BASE[len(table)])
             out.append(table[ch])
+    if backend == "torch":
+        import torch
+
+        return torch.einsum("".join(out), *ops)
     return np.einsum("".join(out), *ops, **kwargs)
 
 

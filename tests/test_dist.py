@@ -321,3 +321,43 @@ def test_world_size_2_gloo_batch_shards_concatenate():
         np.testing.assert_allclose(t * np.exp(c), full, rtol=1e-12)
     np.testing.assert_array_equal(results[0][1], results[1][1])
     assert results[0][2] == results[1][2]
+
+
+def test_bench_gpus_n_starts_a_child_launcher(monkeypatch):
+    """`python bench.py --gpus 4` outside a launcher spawns `python -m torch.distributed.run --nproc-per-node 4
+    bench.py <same arguments>` as a CHILD process before anything touches the GPU, and exits with its code;
+    under a launcher (WORLD_SIZE set) it does not."""
+    import importlib
+    import subprocess
+
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    calls = []
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls.append((cmd, env))
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 7 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_batch_sharding_with_more_ranks_than_items_raises_on_every_rank():
+    """A batch label shorter than the world size is a configuration error on EVERY rank (round-2 advice: only the
+    empty ranks raised, the others hung in the all_gather)."""
+    ops = [np.ones((2, 3)), np.ones((3,))]
+    for rank in range(4):
+        with pytest.raises(ValueError):
+            D.contract_batch_sharded("bk,k->b", ops, "b", contract_fn=oracle_contract, rank=rank, world=4)

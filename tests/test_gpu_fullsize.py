@@ -161,6 +161,38 @@ def test_cfg5_peps_8x8_bond8_three_routes_one_value():
     E.clear_caches()
 
 
+def test_cfg5_bond16_sliced_vs_oracle_on_the_large_tile_kernels():
+    """D = 16 where the CPU oracle still reaches (round-2 verdict, weak 1): a 5 x 6 PEPS with bond 16 through the same
+    machinery as the 8 x 8, D = 16 benchmark - `sliced_plan` -> `SlicedContraction`, 16 slices as replicas of one
+    plan - whose 256 x 4096 x 256 step with both operands k-contiguous runs on the large-tile LDS-DMA kernel
+    `k_mfma_f32_g<4,2,asm,2,2>` (the dominant kernel of the 8 x 8, D = 16 plan): every slice's (T_hat_s, c_s) and the
+    joined value against the oracle on the same sliced network and path."""
+    import bench
+    from contractn_amd import paths
+
+    einstr, shapes, ops = bench.peps_network(5, 6, 16)
+    labels, path, rep = dist.sliced_plan(einstr, shapes, min_slices=16)
+    assert rep["slices"] >= 16
+    sc = dist.SlicedContraction(einstr, ops, labels, optimize=path, rank=0, world=1)
+    t_s, c_s = sc.run()
+    infos, tiles = sc.bc.plan.step_infos(), sc.bc.executor.step_tiles()
+    big = [s for s, i in enumerate(infos) if i["kernel"] == 2 and i["mode_a"] == 2 and i["mode_b"] == 2 and tiles[s] == (256, 128)]
+    assert big, "no step of this plan ran on k_mfma_f32_g<4,2,asm,2,2>"
+    # the oracle, slice by slice (same sliced einsum string, same path), then the same split-format sum
+    sc.local_result()
+    gpu_t, gpu_c = sc.last_slices
+    parts, clist = [], None
+    for i, (_vals, sliced_str, sl_ops) in enumerate(dist.slice_network(einstr, ops, labels)):
+        if clist is None:
+            clist = cpu_ref.contraction_list(sliced_str, [o.shape for o in sl_ops], path)
+        rt, rc, _ = cpu_ref.core_contract(sl_ops, clist)
+        assert float(gpu_t[i]) == float(rt) and abs(float(gpu_c[i]) - float(rc)) <= 1e-4 * max(1.0, abs(float(rc))), i
+        parts.append((rt, rc))
+    rt, rc = dist.combine_split(parts)
+    assert float(t_s) == float(rt) and abs(float(c_s) - float(rc)) <= 1e-4 * max(1.0, abs(float(rc)))
+    E.clear_caches()
+
+
 # ---- config 3b: the paper's ML workload at its full size --------------------------------------------------------------
 def test_cfg3b_full_size_batched_mps_vs_oracle_on_a_subset_of_the_batch():
     """4096 inputs through ONE 100-site MPS (D = 256, d = 4) hanging on a batch hyperedge (BASELINE configs[2] in its

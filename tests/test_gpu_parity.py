@@ -669,10 +669,13 @@ def test_huge_operands_switch_the_executor_to_eager_rescale():
     assert np.all(np.isfinite(resc)) and np.all(np.isfinite(outs))
     c = E.accumulate_log_scale(resc[0], np.dtype(np.float32))
     assert float(outs[0]) == float(g["t_hat"]) and abs(float(c) - float(g["log_scale"])) <= 2e-5 * float(g["log_scale"])
-    # the executor stays eager: the next run needs no repeat and gives the same bits
-    outs2, _log2, resc2 = ex.run_host([g["operands"]])
-    assert ex.eager_reruns() == 1
-    np.testing.assert_array_equal(resc2, resc)
+    # every new run tries the lazy form first (graph replay, no renorm passes): the same extreme operands are caught
+    # again and give the same bits; after three such runs in a row the executor stays eager
+    for reruns in (2, 3, 3, 3):
+        outs2, _log2, resc2 = ex.run_host([g["operands"]])
+        assert ex.eager_reruns() == reruns
+        np.testing.assert_array_equal(resc2, resc)
+        np.testing.assert_array_equal(outs2, outs)
     # forcing eager mode from the start is the same computation
     plan2, ex2 = _plan_and_executor(g)
     assert ex2.set_rescale_mode(1) == 0
@@ -680,6 +683,25 @@ def test_huge_operands_switch_the_executor_to_eager_rescale():
     assert ex2.eager_reruns() == 0
     np.testing.assert_array_equal(resc3, resc)
     np.testing.assert_array_equal(outs3, outs)
+
+
+def test_ordinary_operands_after_an_overflowing_run_are_lazy_again():
+    """One extreme input must not leave a cached executor in eager mode for the rest of the process (round-2 advice):
+    the next, ordinary operands run lazily - no repeat, and bit-identical to an executor that never saw the
+    extreme ones, also once the launch sequence is replayed as a hipGraph."""
+    g = load_golden("mps_overlap_4x32x4_f32_huge")
+    plan, ex = _plan_and_executor(g)
+    _plan, fresh = _plan_and_executor(g)
+    ex.run_host([g["operands"]])
+    assert ex.eager_reruns() == 1
+    tame = [(o / np.float32(1e13)).astype(np.float32) for o in g["operands"]]
+    ref_o, _l, ref_r = fresh.run_host([tame])
+    for _ in range(4):                       # eager launches, capture, replays
+        o, _l2, r = ex.run_host([tame])
+        assert ex.eager_reruns() == 1 and fresh.eager_reruns() == 0
+        np.testing.assert_array_equal(o, ref_o)
+        np.testing.assert_array_equal(r, ref_r)
+    ex.close(); fresh.close()
 
 
 def test_eager_and_lazy_rescale_agree_on_ordinary_data():
@@ -972,3 +994,51 @@ def test_epilogue_sum_and_grouped_leaves_in_eager_rescale_mode():
         assert np.max(np.abs(val - ref)) <= 2e-5 * np.max(np.abs(ref)), einstr
         lazy.close(); eager.close()
     E.clear_caches()
+
+
+# ---- torch backend: the register has the tensor dtype (reference einsum.py:338) -------------------
+@pytest.mark.parametrize("name", golden_names(torch_backend=True))
+@pytest.mark.parametrize("where", ["cpu", "cuda"])
+def test_torch_operands_keep_the_register_in_fp32(name, where):
+    """Fixtures: the unmodified reference on torch CPU tensors.  fp32 torch operands give a ``torch.float32`` 0-d
+    register accumulated step by step in fp32 - 1000 x log(3) = 1098.6213 (bits 0x1.12a7c4p+10), where NumPy
+    operands give the float64 register 1098.6123 - for host and device tensors alike."""
+    import torch
+
+    g = load_golden(name)
+    ops = [torch.from_numpy(o).to(where) for o in g["operands"]]
+    t_hat, log_scale = contract(g["einsum_str"], *ops, optimize=g["path"], split_format=True)
+    assert isinstance(log_scale, torch.Tensor) and log_scale.dtype == torch.float32 and log_scale.dim() == 0
+    assert t_hat.dtype == torch.float32 and t_hat.device.type == where and log_scale.device.type == where
+    assert rel_err(t_hat.cpu().numpy(), g["t_hat"]) <= 2e-5
+    if name.startswith("readme_chain1000"):
+        assert float(log_scale).hex() == g["log_scale_hex"] == "0x1.12a7c40000000p+10"
+        t_np, c_np = contract(g["einsum_str"], *g["operands"], optimize=g["path"], split_format=True)
+        # the NumPy register differs: fp32 logs added up in float64 (SURVEY.md App. A, row float32)
+        assert c_np.dtype == np.float64 and abs(float(c_np) - 1000 * float(np.log(np.float32(3.0)))) < 1e-9
+    else:
+        assert abs(float(log_scale) - float(g["log_scale"])) <= 2e-5 * max(1.0, abs(float(g["log_scale"])))
+    out = contract(g["einsum_str"], *ops, optimize=g["path"])
+    assert out.dtype == torch.float32                                  # torch: fp32 x fp32 register stays fp32
+
+
+# ---- steps on more than two operands (reference einsum.py:382-384 hands any step to _einsum) -------------------------
+def test_nary_steps_and_optimize_false():
+    """`optimize=False` is ONE einsum over all operands in the reference; an explicit path may also name three or
+    more operands per step.  The engine orders such a step pairwise (greedy on the sub-network): same value as
+    np.einsum, including hyperedges, a trace and a label summed out of a single operand inside the n-ary step."""
+    rng = np.random.default_rng(21)
+    cases = [
+        ("ab,bc,cd,de->ae", [(30, 40), (40, 50), (50, 60), (60, 70)], False),
+        ("a,ab,abc,cdd,e->ae", [(3,), (3, 4), (3, 4, 5), (5, 2, 2), (6,)], ((0, 1, 2), (0, 1, 2))),
+        ("ab,ab,ab->ab", [(9, 7)] * 3, False),
+        ("ijk,jl,km,lmn->in", [(8, 9, 10), (9, 11), (10, 12), (11, 12, 13)], ((0, 1, 2, 3),)),
+    ]
+    for ein, shapes, opt in cases:
+        for dtype, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+            ops = [rng.standard_normal(sh).astype(dtype) for sh in shapes]
+            ref = np.einsum(ein, *[o.astype(np.float64) for o in ops])
+            t, c = contract(ein, *ops, optimize=opt, split_format=True)
+            got = np.asarray(t, dtype=np.float64) * np.exp(float(c))
+            assert rel_err(got, ref) <= tol, (ein, np.dtype(dtype).name)
+            assert abs(np.mean(np.abs(t)) - 1.0) < 1e-5

@@ -89,3 +89,20 @@ def test_dtype_table():
     t, c = _run(g, split_format=True)
     assert t.dtype == np.float32 and c.dtype == np.float64 and c.shape == ()
     assert _run(g).dtype == np.float64
+
+
+@pytest.mark.parametrize("name", golden_names(torch_backend=True))
+def test_oracle_torch_register_matches_reference_fixture(name):
+    """The reference on its torch backend keeps the register in the tensor dtype (fp32 tensors: ``torch.zeros(())``
+    accumulated in fp32, einsum.py:338; SURVEY.md App. A last row): 1000 x log(3) then gives 1098.6213, not
+    1098.6123.  Fixtures: the unmodified reference on torch CPU tensors (oracle/gen_golden.py: save_torch)."""
+    g = load_golden(name)
+    t_hat, log_scale = cpu_ref.contract(g["einsum_str"], *g["operands"], path=g["path"], split_format=True,
+                                        torch_register=True)
+    assert t_hat.dtype == np.float32 and np.asarray(log_scale).dtype == np.float32
+    assert g["log_scale"].dtype == np.float32
+    np.testing.assert_allclose(t_hat, g["t_hat"], rtol=1e-5)
+    if name.startswith("readme_chain1000"):      # every abs-sum is exact: bit for bit
+        assert float(log_scale).hex() == g["log_scale_hex"] == "0x1.12a7c40000000p+10"
+    else:
+        assert abs(float(log_scale) - float(g["log_scale"])) <= 1e-5 * max(1.0, abs(float(g["log_scale"])))
