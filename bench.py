@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--max-intermediate", type=int, default=None,
                     help="peps: slice until no intermediate has more elements than this")
     ap.add_argument("--workspace-gib", type=float, default=64.0, help="peps: workspace budget per GPU for slices in flight")
+    ap.add_argument("--plain-slicing", action="store_true",
+                    help="peps: every slice repeats the whole path (dist.SlicedContraction) instead of the staged form, in "
+                         "which slice-independent parts of the tree are contracted once (dist.StagedSlicedContraction)")
     ap.add_argument("--single-gpu-reference", action="store_true",
                     help="peps: rank 0 also measures the best single-GPU form of the same network (unsliced where it fits, "
                          "and the sliced plan on one GPU) and the line reports the speed-up against it")
@@ -573,28 +576,34 @@ def run_peps(args, world, rank, local_rank, backend, dev):
     rows, cols, bond = args.rows, args.cols, args.bond
     einstr, shapes, ops = peps_network(rows, cols, bond)
     # slice labels + path: found once (rank 0; cached under contractn_amd/plans/), shared with every rank
+    staged = not args.plain_slicing
     box = [None]
     t0 = time.perf_counter()
     if rank == 0:
-        box[0] = cdist.sliced_plan(einstr, shapes, min_slices=args.slices, max_intermediate=args.max_intermediate)
+        if staged:
+            box[0] = cdist.staged_plan(einstr, shapes, min_slices=args.slices, max_intermediate=args.max_intermediate)
+        else:
+            box[0] = cdist.sliced_plan(einstr, shapes, min_slices=args.slices, max_intermediate=args.max_intermediate)
     if world > 1:
         dist.broadcast_object_list(box, src=0)
     labels, path, rep = box[0]
     search_s = time.perf_counter() - t0
-    sc = cdist.SlicedContraction(einstr, ops, labels, optimize=path, rank=rank, world=world, device=local_rank,
-                                 workspace_budget=int(args.workspace_gib * 2 ** 30))
-    ex = sc.bc.executor if sc.bc is not None else None
-    n_chunks = len(sc._chunks)
+    make = cdist.StagedSlicedContraction if staged else cdist.SlicedContraction
+    sc = make(einstr, ops, labels, optimize=path, rank=rank, world=world, device=local_rank,
+              workspace_budget=int(args.workspace_gib * 2 ** 30))
+    stages = sc.stage_list()          # [(BatchedContraction, evaluations on this rank, replicas per launch, launches)]
+    execs = [st[0].executor for st in stages]
+    max_chunks = max([st[3] for st in stages], default=1)
 
     def sync_all():
-        if ex is not None:
-            ex.synchronize()
+        for x in execs:
+            x.synchronize()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
 
     # (an executor replays its launch sequence as a hipGraph from its third enqueue on: at least two eager ones first)
-    for _ in range(max(0, 2 - args.warmup * max(n_chunks, 1))):
+    for _ in range(max(0, 2 - args.warmup * max(max_chunks, 1))):
         sc.run()
     for _ in range(args.warmup):
         sc.run()
@@ -602,8 +611,8 @@ def run_peps(args, world, rank, local_rank, backend, dev):
 
     # ---- timed region: exactly K contractions, join included -------------------------------
     timed_passes = min(args.steps, args.event_passes)
-    if ex is not None:
-        ex.set_timing(timed_passes * n_chunks)
+    for x, st in zip(execs, stages):
+        x.set_timing(timed_passes * st[3])
     sync_all()
     sampler = PowerSampler(dev) if rank == 0 else None
     t0 = time.perf_counter()
@@ -612,42 +621,49 @@ def run_peps(args, world, rank, local_rank, backend, dev):
     sync_all()
     elapsed = time.perf_counter() - t0
     under_load = sampler.stop() if sampler else {}
-    step_ms = ex.step_ms().astype(np.float64) if ex is not None else None
-    if ex is not None:
-        ex.set_timing(0)
+    stage_ms = [x.step_ms().astype(np.float64) for x in execs]     # per step: mean over the recorded launches
+    for x in execs:
+        x.set_timing(0)
+    # evaluations per stage over all ranks (a stage below no sliced label is evaluated by every rank: counted each time)
+    evals_all = torch.tensor([float(st[1]) for st in stages], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        dist.all_reduce(evals_all, op=dist.ReduceOp.SUM)
+    evals_all = evals_all.cpu().numpy()
     if rank != 0:
         return None
 
-    plan = sc.bc.plan
-    infos = plan.step_infos()
     value = args.steps / elapsed
-    flop_sliced = plan.flops * sc.n_total
+    # work of one contraction over ALL ranks: every stage's plan x its evaluations (a staged plan evaluates a stage
+    # once per joint value of the sliced labels it depends on; plain slicing: one stage, once per slice)
+    sizes = sc.sizes
+    n_eval_total = [int(x) for x in evals_all]
+    flop_sliced = float(sum(st[0].plan.flops * n for st, n in zip(stages, n_eval_total)))
     tflops = value * flop_sliced / 1e12
 
-    # ---- roofline of the dominant kernel on rank 0 (per launch of R slices, HIP-event durations) ---------
+    # ---- roofline of the dominant kernel on rank 0 (per launch of R evaluations, HIP-event durations) ---------
     # algorithmic bytes of a step: both operands and the output once, from the step's own einsum string
-    sizes = sc.sizes
-    step_bytes = []
-    for c in sc.bc.contract_list:
-        lhs, out = c[2].split("->")
-        step_bytes.append(4 * sum(int(np.prod([sizes[x] for x in set(t)])) if t else 1 for t in lhs.split(",") + [out]))
-    tiles = ex.step_tiles()
-    by_kernel = {}
-    for s_, info in enumerate(infos):
-        key = (info["kernel"], info["mode_a"], info["mode_b"], tiles[s_][0], tiles[s_][1])
-        d = by_kernel.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
-        d["ms"] += step_ms[s_]
-        d["flops"] += info["flops"] * sc.R
-        d["bytes"] += step_bytes[s_] * sc.R
-        d["launches"] += 1
+    by_kernel, dump = {}, []
+    for k_, ((bc_, n_loc, R_, chunks_), ms_) in enumerate(zip(stages, stage_ms)):
+        infos = bc_.plan.step_infos()
+        tiles = bc_.executor.step_tiles()
+        for s_, (info, c) in enumerate(zip(infos, bc_.contract_list)):
+            lhs, out = c[2].split("->")
+            nbytes = 4 * sum(int(np.prod([sizes[x] for x in set(t)])) if t else 1 for t in lhs.split(",") + [out])
+            key = (info["kernel"], info["mode_a"], info["mode_b"], tiles[s_][0], tiles[s_][1])
+            d = by_kernel.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+            d["ms"] += ms_[s_] * chunks_               # per contraction (rank 0): the step's mean launch x its launches
+            d["flops"] += info["flops"] * R_ * chunks_
+            d["bytes"] += nbytes * R_ * chunks_
+            d["launches"] += chunks_
+            dump.append(dict(info, stage=k_, ms=float(ms_[s_]), bytes=nbytes, replicas=R_, launches=chunks_,
+                             tile=list(tiles[s_]), einsum=c[2]))
+    plan = stages[-1][0].plan
     if args.dump_steps:
         with open(args.dump_steps, "w") as fh:
-            json.dump([dict(info, ms=float(step_ms[s_]), bytes=step_bytes[s_], replicas=sc.R, tile=list(tiles[s_]),
-                            einsum=sc.bc.contract_list[s_][2]) for s_, info in enumerate(infos)], fh)
+            json.dump(dump, fh)
     dom_key = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
     dom = by_kernel[dom_key]
     mfma = dom_key[0] in (2, 3)
@@ -668,7 +684,7 @@ def run_peps(args, world, rank, local_rank, backend, dev):
         "traffic": None,
         "traffic_source": None,
         "arithmetic_intensity_flop_per_byte": round(ai, 2),
-        "launches_per_contraction": dom["launches"] * n_chunks,
+        "launches_per_contraction": dom["launches"],
         "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
         "share_of_device_time": round(dom["ms"] / total_ms, 4) if total_ms > 0 else None,
         "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
@@ -703,10 +719,17 @@ def run_peps(args, world, rank, local_rank, backend, dev):
             "slices_per_gpu": len(sc.my_slices),
             "sliced_labels": len(labels),
             "slices_in_flight_per_launch": sc.R,
+            "outer_labels_walked_on_the_host": getattr(sc, "outer", 0),
+            "execution": ("staged: a stage of the tree is evaluated once per joint value of the sliced labels below it "
+                          "(dist.StagedSlicedContraction)" if staged else "plain: every slice repeats the whole path"),
+            "stages": [{"depends_on_sliced_labels": len(sc.stage_desc[k]["dep"]) if staged else len(labels),
+                        "evaluations": n_eval_total[k], "evaluations_on_rank0": stages[k][1], "steps": stages[k][0].plan.n_steps,
+                        "flop_per_evaluation": stages[k][0].plan.flops} for k in range(len(stages))],
             "work_overhead_vs_unsliced": round(rep["work_overhead"], 3),
+            "work_overhead_if_every_slice_repeated_everything": round(rep.get("plain_overhead", rep["work_overhead"]), 3),
             "largest_intermediate_elements": rep["largest_intermediate"],
             "unsliced_largest_intermediate_elements": rep["unsliced_largest_intermediate"],
-            "steps_per_slice": plan.n_steps,
+            "steps_per_slice": plan.n_steps if not staged else sum(st_[0].plan.n_steps for st_ in stages),
             "flop_per_contraction_sliced": flop_sliced,
             "multiply_adds_unsliced_path": rep["unsliced_flops"],
             "slice_search_s": round(search_s, 2),
@@ -722,7 +745,7 @@ def run_peps(args, world, rank, local_rank, backend, dev):
         if rep["unsliced_largest_intermediate"] <= 2 ** 28:
             result["unsliced_check"] = peps_unsliced_check(einstr, shapes, ops, float(t_hat), float(log_scale), local_rank)
     if getattr(args, "single_gpu_reference", False):
-        del sc, ex
+        del sc, execs, stages
         torch.cuda.empty_cache()
         result["strong_scaling"] = peps_single_gpu_reference(args, einstr, shapes, ops, labels, path, rep, local_rank,
                                                              world, elapsed / args.steps, float(t_hat), float(log_scale))
@@ -750,8 +773,9 @@ def peps_single_gpu_reference(args, einstr, shapes, ops, labels, path, rep, devi
     if world == 1:
         sliced_ms = sec_per_step * 1e3
     else:
-        sc1 = cdist.SlicedContraction(einstr, ops, labels, optimize=path, rank=0, world=1, device=device,
-                                      workspace_budget=int(args.workspace_gib * 2 ** 30))
+        make = cdist.SlicedContraction if args.plain_slicing else cdist.StagedSlicedContraction
+        sc1 = make(einstr, ops, labels, optimize=path, rank=0, world=1, device=device,
+                   workspace_budget=int(args.workspace_gib * 2 ** 30))
         reps = 1 if sec_per_step * world > 1.0 else max(3, args.steps)
         for _ in range(0 if reps == 1 else 3):
             sc1.run()
@@ -808,8 +832,7 @@ def peps_cpu_baseline(sc, einstr, ops, labels, path, budget_s):
         threads = max((p.get("num_threads", 1) for p in threadpool_info()), default=1)
     except Exception:
         threads = os.cpu_count()
-    sc.local_result()                 # per-slice values through the checked host path (run() joins on the device)
-    gpu_t, gpu_c = sc.last_slices
+    gpu_t, gpu_c = sc.slices_host()   # per-slice values (run() itself joins them on the device)
     n, worst, signs_ok, spent, clist = 0, 0.0, True, 0.0, None
     for i, (_vals, sliced_str, sl_ops) in enumerate(cdist.slice_network(einstr, ops, labels)):
         if i >= len(sc.my_slices):

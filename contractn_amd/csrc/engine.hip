@@ -30,6 +30,7 @@
 #include "kernels_mfma.h"
 #include "kernels_mfma_g.h"
 #include "kernels_mfma_g64.h"
+#include "kernels_mfma_h.h"
 #include "kernels_mfma_lat.h"
 #include "kernels_stream.h"
 
@@ -55,6 +56,7 @@ struct DevSwitches {
   int splitk = -1;       // CTN_SPLITK: 0 disables the latency mode, 1 forces it for every eligible step (tests)
   int splitk_max = 0;    // CTN_SPLITK_MAX: tile-count threshold of the latency mode
   int lat = -1;          // CTN_LAT: 0 never use the one-launch latency form (k_mfma_f32_lat), 1 whenever the shape allows (tests)
+  int hform = -1;        // CTN_H: 0 never use the one-tile-per-CU form (k_mfma_f32_h), 1 whenever the shape allows (tests)
   bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
   const char* stamps = nullptr;  // CTN_DEBUG_STAMPS=<file> (make STAMPS=1 builds): dump in-kernel cycle stamps
   int stamp_step = -1;   // CTN_DEBUG_STAMP_STEP=<s>: stamp only this step
@@ -69,6 +71,7 @@ static DevSwitches read_dev_switches() {
   d.splitk = num("CTN_SPLITK", -1);
   d.splitk_max = num("CTN_SPLITK_MAX", 0);
   d.lat = num("CTN_LAT", -1);
+  d.hform = num("CTN_H", -1);
   d.lat64_min_k = num("CTN_LAT64_MIN_K", 512);
   d.splitk_fill_long = num("CTN_SPLITK_FILL_LONG", 2);
   d.lat_max_t = num("CTN_LAT_MAX_T", 64);
@@ -260,7 +263,9 @@ static void launch_mfma(int ma, int mb, int tile_m, int tile_n, dim3 grid, hipSt
 // Latency mode (see k_mfma_f32_sk): chosen when the 128-wide tiles of a step cannot occupy half the
 // chip.  Returns the number of K splits (0 = use the throughput kernel).  CTN_SPLITK=0 disables,
 // CTN_SPLITK=1 forces it for every eligible step (tests).
+static bool h_forced(const Step& st, int dtype, const DevSwitches& sw);
 static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
+  if (h_forced(st, dtype, sw)) return 0;
   const int mode = sw.splitk;
   const bool mfma = (dtype == CTN_F32 && st.kernel == CTN_KERNEL_MFMA_F32) || (dtype == CTN_F64 && st.kernel == CTN_KERNEL_MFMA_F64);
   if (mode == 0 || !mfma || st.collapse || st.K < 128 || st.modeA >= 3 || st.epw) return 0;
@@ -288,6 +293,7 @@ static int splitk_splits(const Step& st, int R, int n_cu, int dtype, const DevSw
 // at most kLatMaxTiles tiles per replica (one abs-sum partial each), both k-offset tables in LDS.
 constexpr int kLatMaxTiles = kMaxPartials;
 static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw) {
+  if (h_forced(st, dtype, sw)) return 0;           // tests of the one-tile-per-CU form (CTN_H=1)
   const bool f64 = dtype == CTN_F64 && st.kernel == CTN_KERNEL_MFMA_F64;
   if (sw.lat == 0 || !(f64 || (dtype == CTN_F32 && st.kernel == CTN_KERNEL_MFMA_F32)) || st.rhs < 0 || st.modeA >= 3 || st.epw) return 0;
   if (st.K > kLatMaxK || st.K < 32) return 0;
@@ -314,6 +320,32 @@ static int lat_form(const Step& st, int R, int n_cu, int dtype, const DevSwitche
   // 256 x 1024 x 256: 3.47 -> 3.28 / 3.62 -> 3.44 ms per 100-site network)
   if (sw.lat_max_t >= 64 && 2 * t64 * R >= n_cu && fits(t64) && st.K <= 256 && !kcontig) return 64;   // (a long K is better off split over workgroups)
   return 0;
+}
+
+// CTN_H=1 (tests): a step whose SHAPE admits the one-tile-per-CU form takes it whatever the launch size - the latency
+// forms step aside (the remaining conditions - vector-storable C, not the last step - are checked by h_form itself)
+static bool h_forced(const Step& st, int dtype, const DevSwitches& sw) {
+  return sw.hform == 1 && dtype == CTN_F32 && st.kernel == CTN_KERNEL_MFMA_F32 && st.rhs >= 0 && !st.collapse &&
+         st.modeA >= 1 && st.modeA <= 2 && st.modeB >= 1 && st.modeB <= 2 && st.K % 32 == 0 && st.K >= 64 && st.cvec &&
+         (st.epw ? (st.epw_split && (st.epw == 2 || st.epw == 4)) : st.lhs2 < 0) &&
+         st.Bt * ((st.M + 127) / 128) * ((st.N + 127) / 128) <= kMaxPartials;
+}
+
+// One-tile-per-CU form (k_mfma_f32_h, kernels_mfma_h.h): 128 x 128 tiles, K split over the two halves of an 8-wave
+// workgroup.  Taken when the step's 128 x 128 tiles are about one round of one workgroup per CU - between half a chip
+// and a whole one - which is where the register-staged kernel's 128 x 64 tiles run as a single round of two small
+// workgroups per CU and the large-tile kernel would leave CUs idle (one MPS site applied to 4096 inputs: 256 tiles).
+static bool h_form(const Plan& P, const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw, bool c_vec) {
+  if (sw.hform == 0 || dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.rhs < 0 || st.collapse) return false;
+  if (st.modeA < 1 || st.modeA > 2 || st.modeB < 1 || st.modeB > 2) return false;      // LDS-DMA: 16-byte requests only
+  if (st.epw ? !(st.epw_split && (st.epw == 2 || st.epw == 4)) : st.lhs2 >= 0) return false;
+  if (st.K % 32 != 0 || st.K < 64 || !c_vec) return false;
+  if (P.tensors[st.lhs].numel > (1LL << 30) || P.tensors[st.rhs].numel > (1LL << 30)) return false;   // 32-bit byte offsets
+  const int64_t t128 = st.Bt * ((st.M + 127) / 128) * ((st.N + 127) / 128);
+  if (t128 > kMaxPartials) return false;
+  if (sw.hform == 1) return true;
+  if (sw.mfma_g >= 2 && st.tileM == 256) return false;     // tests that force the large-tile kernels
+  return 2 * t128 * R >= n_cu && t128 * R <= n_cu;
 }
 
 // Tile of the register-staged fp32 kernel for this step and replica count: the planner's 128 / 64 choice, halved
@@ -581,6 +613,36 @@ static int exec_launch_steps(Exec* E) {
           used_tile(64, 64);
           launch_sk(st.modeA, st.modeB, dim3((unsigned)((int64_t)sk.tiles_per_replica * sk.S * R)), E->stream, a, sk);
           launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
+          break;
+        }
+        if (!g_launch(st, R, E->n_cu, E->mfma_g) && s + 1 < P.n_steps && h_form(P, st, R, E->n_cu, P.dtype, E->sw, a.c_vec != 0)) {
+          a.tiles_m = (int32_t)((st.M + 127) / 128);
+          a.tiles_n = (int32_t)((st.N + 127) / 128);
+          a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n);
+          a.partC = part_dst; a.partC_stride = part_stride; do_collapse = false;   // one partial per tile (<= kMaxPartials)
+          if (E->sw.stamps && (E->sw.stamp_step < 0 || E->sw.stamp_step == s)) {
+            const size_t need = (size_t)a.blocks_per_replica * R;
+            if (E->dbg_tiles < need) {
+              if (E->d_dbg) (void)hipFree(E->d_dbg);
+              HIPCHECK(hipMalloc((void**)&E->d_dbg, need * 64));
+              E->dbg_tiles = need;
+            }
+            a.dbg = E->d_dbg;
+            HIPCHECK(hipMemsetAsync(E->d_dbg, 0, E->dbg_tiles * 64, E->stream));
+          }
+          used_tile(128, 128);
+          const dim3 gh((unsigned)((int64_t)a.blocks_per_replica * R));
+#define CTN_H_LAUNCH(AA, BB)                                                                              \
+          do {                                                                                            \
+            if (st.epw == 4) hipLaunchKernelGGL((k_mfma_f32_h<AA, BB, 4>), gh, dim3(512), 0, E->stream, a);      \
+            else if (st.epw == 2) hipLaunchKernelGGL((k_mfma_f32_h<AA, BB, 2>), gh, dim3(512), 0, E->stream, a); \
+            else hipLaunchKernelGGL((k_mfma_f32_h<AA, BB, 0>), gh, dim3(512), 0, E->stream, a);                  \
+          } while (0)
+          if (st.modeA == 2 && st.modeB == 2) CTN_H_LAUNCH(2, 2);
+          else if (st.modeA == 2) CTN_H_LAUNCH(2, 1);
+          else if (st.modeB == 2) CTN_H_LAUNCH(1, 2);
+          else CTN_H_LAUNCH(1, 1);
+#undef CTN_H_LAUNCH
           break;
         }
         a.tiles_n = (int32_t)((st.N + st.tileN - 1) / st.tileN);
@@ -1103,6 +1165,9 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     else if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
                           rowdot_splits(st, replicas, E.n_cu)))
       E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kWaveOutputs, P.tensors[st.out].numel / 1024));
+    else if (!g_launch(st, replicas, E.n_cu, E.mfma_g) && s + 1 < P.n_steps &&
+             h_form(P, st, replicas, E.n_cu, P.dtype, E.sw, st.cvec))
+      E.step_partials[s] = (int)(st.Bt * ((st.M + 127) / 128) * ((st.N + 127) / 128));
     else if (st.kernel == CTN_KERNEL_MFMA_F32 && !st.collapse) {
       int tm, tn;
       plain_tiles(st, replicas, E.n_cu, E.mfma_g, s + 1 == P.n_steps, &tm, &tn, E.sw.halve);

@@ -800,6 +800,16 @@ class SlicedContraction:
         self.last_slices = None   # (T_hat [n_local, ...], log_scale [n_local]) of the last local_result()
         self._join = None         # device / pinned buffers of run_small, allocated on first use
 
+    def slices_host(self):
+        """``(T_hat [n_local, ...], c [n_local])`` of this rank's slices, through the checked host path."""
+        self.local_result()
+        return self.last_slices
+
+    def stage_list(self):
+        """``[(BatchedContraction, evaluations on this rank, replicas per launch, launches per contraction)]`` - one
+        entry here; `StagedSlicedContraction` has one per stage (measurement tooling: bench.py)."""
+        return [] if self.bc is None else [(self.bc, len(self.my_slices), self.R, len(self._chunks))]
+
     def local_result(self):
         """Run this rank's slices group by group and combine them (split format); an exact zero
         when the rank owns none."""
@@ -881,22 +891,7 @@ class SlicedContraction:
                 host = np.concatenate([np.asarray(t_loc, dtype=np.float64).ravel(), [float(c_loc)]])
                 J["packed"].copy_(torch.from_numpy(host))
                 torch.cuda.current_stream(dev).synchronize()
-            result = J["packed"]
-            if self.world > 1:
-                if dist.get_backend(group) == "nccl":
-                    dist.all_gather_into_tensor(J["gathered"], J["packed"], group=group)      # THE join
-                else:   # gloo (CPU tests, one-GPU rehearsals): the same buffer crosses through the host
-                    send = J["packed"].cpu()
-                    recv = [torch.empty_like(send) for _ in range(self.world)]
-                    dist.all_gather(recv, send, group=group)
-                    J["gathered"].copy_(torch.cat(recv))
-                torch.cuda.current_stream(dev).synchronize()
-                g = J["gathered"].data_ptr()
-                ex.combine_split(g, numel + 1, g + 8 * numel, numel + 1, self.world, numel, J["final"].data_ptr(),
-                                 dtype=np.float64)
-                ex.synchronize()
-                result = J["final"]
-            host = result.cpu().numpy()
+            host = join_packed(ex, J, self.world, group, dev)
         t = host[:numel].reshape(self.out_shape).astype(self.np_dtype)
         return t, np.asarray(host[numel], dtype=np.float64)
 
@@ -987,6 +982,621 @@ class SlicedContraction:
             norm = torch.tensor([norm_v])
         c = c_star + (float(np.log(rescale)) if float(norm.item()) > 1e-7 else 0.0)
         return full.reshape(self.out_shape), c
+
+
+def join_packed(ex, J, world, group, dev):
+    """The cross-rank half of the device-side join: ``J["packed"]`` (this rank's ``numel + 1`` doubles, complete and
+    visible: the executor's stream has been waited for) -> ONE ``all_gather`` -> `k_combine_split` over the ``world``
+    parts -> the packed result on the host."""
+    import torch
+    import torch.distributed as dist
+
+    numel = J["numel"]
+    result = J["packed"]
+    if world > 1:
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(J["gathered"], J["packed"], group=group)      # THE join
+        else:   # gloo (CPU tests, one-GPU rehearsals): the same buffer crosses through the host
+            send = J["packed"].cpu()
+            recv = [torch.empty_like(send) for _ in range(world)]
+            dist.all_gather(recv, send, group=group)
+            J["gathered"].copy_(torch.cat(recv))
+        torch.cuda.current_stream(dev).synchronize()
+        g = J["gathered"].data_ptr()
+        ex.combine_split(g, numel + 1, g + 8 * numel, numel + 1, world, numel, J["final"].data_ptr(), dtype=np.float64)
+        ex.synchronize()
+        result = J["final"]
+    return result.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------
+# staged slicing: slice-independent work is done once
+# ---------------------------------------------------------------------------
+def stage_decomposition(einstr, shapes, slice_labels, path, min_saved=1 << 28):
+    """Cut the contraction tree of ``path`` into STAGES by the sliced labels each node depends on.
+
+    A node of the tree depends on a sliced label when one of the leaves below it carries that label; nodes with the
+    same dependency set that hang together form a stage, and a stage is evaluated once per joint value of ITS labels,
+    not once per slice: a subtree that touches no sliced label is contracted a single time, one that touches only the
+    first label ``extent(first)`` times, and only the top of the tree - the root stage, which depends on all of them -
+    once per slice.  Plain slicing repeats everything for every slice (8 x 8 PEPS, D = 8, 64 slices: 2.1 x the unsliced
+    work; the same labels and tree in stages: 1.46 x, and 1.25 x when tree and labels are searched for this form,
+    `choose_staged_slices`).
+
+    Returns the stages in execution order (operands before their consumer), each a dict::
+
+        dep       labels the stage depends on, in the order of ``slice_labels``
+        operands  [("in", i) | ("st", k)]: network input i, or the result of stage k
+        einsum    einsum string over those operands with every sliced label removed (it is fixed per evaluation)
+        path      linear path over the stage's operands
+        out       labels of the stage's result (the network's output for the last, the root stage)
+
+    A subtree is given a stage of its own only when that saves at least ``min_saved`` multiply-adds (its work times
+    the evaluations it is spared); below that it stays inside its consumer and is simply recomputed - a stage is a
+    plan, an executor and a handful of launches (the 64 physical-leg absorptions of an 8 x 8 PEPS depend on no
+    sliced label and are far too small to earn one each; inside their consumer they go out as ONE grouped launch).
+
+    Pure host function; ``path`` indexes the network's operands (a sliced label keeps its place in the operand list:
+    the sliced network has the same operands)."""
+    shapes = [tuple(int(d) for d in sh) for sh in shapes]
+    terms, out, sizes = paths.parse_einsum_input(einstr, shapes)
+    sl = list(slice_labels)
+    for lab in sl:
+        if lab in out or lab not in sizes:
+            raise ValueError(f"cannot slice over label '{lab}'")
+    n = len(terms)
+    sets = [set(t) for t in terms]
+    total = {}
+    for t in sets:
+        for lab in t:
+            total[lab] = total.get(lab, 0) + 1
+    # the tree: leaves 0..n-1, internal nodes n.. in path order
+    kids, count, dep = {}, {i: {lab: 1 for lab in t} for i, t in enumerate(sets)}, {}
+    for i, t in enumerate(sets):
+        dep[i] = frozenset(lab for lab in sl if lab in t)
+    live, nxt = list(range(n)), n
+    for step in path:
+        step = tuple(sorted(int(p_) for p_ in step))
+        if len(step) == 1:
+            continue        # (a unary step belongs to its operand; the engine's path search emits none for n > 1)
+        if len(step) != 2:
+            raise NotImplementedError("stage_decomposition needs a pairwise path")
+        a, b = live[step[0]], live[step[1]]
+        live = [x for k, x in enumerate(live) if k not in step] + [nxt]
+        kids[nxt] = (a, b)
+        c = dict(count[a])
+        for lab, v in count[b].items():
+            c[lab] = c.get(lab, 0) + v
+        count[nxt] = c
+        dep[nxt] = dep[a] | dep[b]
+        nxt += 1
+    if len(live) != 1:
+        raise ValueError("path does not reduce the network to a single tensor")
+    root = live[0]
+    out_set = set(out)
+
+    def labels_of(v):
+        if v < n:
+            return set(sets[v])
+        return {lab for lab, c in count[v].items() if lab in out_set or c < total[lab]}
+
+    def result_term(v):
+        if v == root:
+            return out
+        keep = labels_of(v) - set(sl)
+        return "".join(lab for _d, lab in sorted((sizes[lab], lab) for lab in keep))
+
+    sz1 = dict(sizes)
+    for lab in sl:
+        sz1[lab] = 1
+
+    def evaluations(d):
+        e = 1
+        for lab in d:
+            e *= sizes[lab]
+        return e
+
+    sub_work = {}
+
+    def work_below(v):     # multiply-adds of ONE evaluation of the whole subtree under v (sliced extents)
+        if v < n:
+            return 0
+        if v not in sub_work:
+            a, b = kids[v]
+            sub_work[v] = work_below(a) + work_below(b) + paths._size(labels_of(a) | labels_of(b), sz1)
+        return sub_work[v]
+
+    stages, stage_of = [], {}
+
+    def build(r):
+        """The stage rooted at internal node r (its operands' stages first)."""
+        operands, op_terms, pairs = [], [], []
+        ids = {}
+
+        def walk(v):
+            if v < n:
+                ids[v] = len(operands)
+                operands.append(("in", v))
+                op_terms.append("".join(lab for lab in terms[v] if lab not in sl))
+                return
+            if v != r and dep[v] != dep[r] and work_below(v) * (evaluations(dep[r]) - evaluations(dep[v])) >= min_saved:
+                if v not in stage_of:
+                    build(v)
+                ids[v] = len(operands)
+                operands.append(("st", stage_of[v]))
+                op_terms.append(stages[stage_of[v]]["out"])
+                return
+            for c in kids[v]:
+                walk(c)
+
+        walk(r)
+        n_ops = len(operands)
+        steps = []
+
+        def emit(v):
+            if v in ids:
+                return ids[v]
+            a, b = (emit(c) for c in kids[v])
+            ids[v] = n_ops + len(steps)
+            steps.append((a, b))
+            return ids[v]
+
+        emit(r)
+        res = result_term(r)
+        stage_of[r] = len(stages)
+        stages.append({"dep": tuple(lab for lab in sl if lab in dep[r]), "operands": operands,
+                       "einsum": ",".join(op_terms) + "->" + res, "path": tuple(paths._ssa_pairs_to_linear(steps, n_ops)),
+                       "out": res})
+
+    if root < n:
+        raise ValueError("a single-operand network has nothing to stage")
+    build(root)
+    return stages
+
+
+def choose_staged_slices(einstr, shapes, min_slices=1, max_intermediate=None, parallel=8, max_held=1 << 34, max_labels=6,
+                         seeds=4, rounds=8, first_seed=0):
+    """Slice labels and contraction tree for STAGED execution (`stage_decomposition`), chosen together.
+
+    Objective: ``paths.hoisted_cost(..., parallel)`` - every node of the tree costs its sliced index space times the
+    number of joint values of the sliced labels BELOW it, and at least ``parallel`` evaluations (work that cannot be
+    dealt to ``parallel`` ranks is replicated on them) - subject to at least ``min_slices`` slices, no tensor above
+    ``max_intermediate`` elements and at most ``max_held`` elements held between stages.  Search, per seed: a tree
+    (the library's own path for seed 0, refined noisy-greedy trees for the others), then alternately (a) the label set
+    on that tree - greedy by the objective, then swaps and removals until none helps - and (b) subtree
+    reconfiguration of the tree for those labels under the same objective (`paths._reconfigure(slice_labels=...)`),
+    until neither moves.  The best seed wins (``first_seed``: where the seed range starts, for searches spread over
+    processes - tools/make_plans.py).  Returns ``(labels, path, report)`` like `choose_slices_with_path`;
+    ``report["work_overhead"]`` is total work over all evaluations / unsliced work, ``report["plain_overhead"]`` what
+    the same labels and tree cost when every slice repeats everything.  When materialising every stage for all its
+    evaluations would hold more than ``max_held`` elements (8 x 8 PEPS, D = 16: stage results of 2^28 elements each),
+    the first ``report["outer_labels"]`` of the returned labels are meant to be walked in a host loop, one value at
+    a time (`StagedSlicedContraction(outer=...)`), and the label ORDER is chosen with that count so that what has to be
+    recomputed per outer value costs least (`paths.hoisted_profile`).  Host-only, deterministic."""
+    shapes = [tuple(int(d) for d in sh) for sh in shapes]
+    terms, out, sizes = paths.parse_einsum_input(einstr, shapes)
+    sets = [set(t) for t in terms]
+    cands = sorted(lab for lab in sizes if lab not in out and sizes[lab] > 1)
+
+    plan_of = {}     # (labels in search order) -> (labels in loop order, outer) of the last measurement
+
+    def measure(path, labels):
+        """Objective and constraints for this label SET: everything materialised at once when that fits ``max_held``,
+        otherwise the cheapest (loop order, number of outer labels walked on the host) that does."""
+        cnt = 1
+        for lab in labels:
+            cnt *= sizes[lab]
+        tot, big, _one, held = paths.hoisted_profile(sets, out, sizes, path, labels, parallel=parallel)
+        plan_of[tuple(labels)] = (tuple(labels), 0)
+        if held > max_held and 0 < len(labels) <= 4:
+            best_ = None
+            for order in itertools.permutations(labels):
+                for outer in range(1, len(labels) + 1):
+                    t2, b2, _o, h2 = paths.hoisted_profile(sets, out, sizes, path, order, parallel=parallel, outer=outer)
+                    key = (h2 > max_held, t2 if h2 <= max_held else h2, outer, order)
+                    if best_ is None or key < best_[0]:
+                        best_ = (key, t2, b2, h2, order, outer)
+            _k, tot, big, held, order, outer = best_
+            plan_of[tuple(labels)] = (tuple(order), outer)
+        return tot, big, cnt, held
+
+    def feasible(big, cnt, held):
+        return cnt >= min_slices and (max_intermediate is None or big <= max_intermediate) and held <= max_held
+
+    def violation(big, cnt, held):
+        v = 0.0
+        if max_intermediate is not None and big > max_intermediate:
+            v += big / max_intermediate
+        if held > max_held:
+            v += held / max_held
+        return v
+
+    def pick_labels(path, start):
+        labels = list(start)
+        tot, big, cnt, held = measure(path, labels)
+        while not feasible(big, cnt, held) and len(labels) < max_labels:
+            best = None
+            for lab in cands:
+                if lab in labels:
+                    continue
+                t2, b2, c2, h2 = measure(path, labels + [lab])
+                key = (violation(b2, c2, h2), t2, lab)
+                if best is None or key < best[0]:
+                    best = (key, lab)
+            if best is None:
+                break
+            labels.append(best[1])
+            tot, big, cnt, held = measure(path, labels)
+        moved = feasible(big, cnt, held)
+        while moved:
+            moved = False
+            for i in range(len(labels)):
+                for lab in cands:
+                    if lab in labels:
+                        continue
+                    trial = labels[:i] + [lab] + labels[i + 1:]
+                    t2, b2, c2, h2 = measure(path, trial)
+                    if feasible(b2, c2, h2) and t2 < tot:
+                        labels, tot, big, cnt, held, moved = trial, t2, b2, c2, h2, True
+            for i in range(len(labels)):
+                trial = labels[:i] + labels[i + 1:]
+                t2, b2, c2, h2 = measure(path, trial)
+                if feasible(b2, c2, h2) and t2 < tot:
+                    labels, tot, big, cnt, held, moved = trial, t2, b2, c2, h2, True
+                    break
+        return labels, tot, big, cnt, held
+
+    base_path = paths.find_path(terms, out, sizes, "auto")
+    base_flops, base_big = paths.path_cost(sets, out, sizes, base_path)
+    best = None
+    for seed in range(first_seed, first_seed + max(1, seeds)):
+        if seed == 0:
+            path = base_path
+        else:
+            path = paths._reconfigure(sets, out, sizes, paths._random_greedy(sets, out, sizes, repeats=4, seed=seed),
+                                      max_leaves=8, rounds=8)
+        labels = []
+        for _ in range(rounds):
+            labels, tot, big, cnt, held = pick_labels(path, labels)
+            if feasible(big, cnt, held) and (best is None or (tot, big) < best[0]):
+                best = ((tot, big), tuple(labels), path, cnt, held)
+            path2 = paths._reconfigure(sets, out, sizes, path, max_leaves=8, rounds=8, memory_limit=max_intermediate,
+                                       slice_labels=labels, parallel=parallel)
+            t2, b2, c2, h2 = measure(path2, labels)
+            if feasible(b2, c2, h2) and (best is None or (t2, b2) < best[0]):
+                best = ((t2, b2), tuple(labels), path2, c2, h2)
+            if t2 >= tot:
+                break
+            path = path2
+    if best is None:
+        raise ValueError("no feasible staged slicing found: relax max_intermediate / max_held or allow more labels")
+    (tot, big), labels, path, cnt, held = best
+    measure(path, list(labels))
+    labels, outer = plan_of[tuple(labels)]      # loop order: the first `outer` labels are walked on the host
+    work, _b, one, held = paths.hoisted_profile(sets, out, sizes, path, labels, parallel=1, outer=outer)
+    report = {"slices": cnt, "largest_intermediate": big, "unsliced_largest_intermediate": base_big,
+              "work_overhead": work / max(base_flops, 1), "plain_overhead": one * cnt / max(base_flops, 1),
+              "modelled_overhead_at_parallel": tot / max(base_flops, 1), "parallel": parallel, "outer_labels": outer,
+              "held_between_stages": held, "unsliced_flops": base_flops, "staged": True}
+    return tuple(labels), tuple(tuple(int(x) for x in p_) for p_ in path), report
+
+
+def staged_plan(einstr, shapes, min_slices=1, max_intermediate=None, cache_dir=None, **kwargs):
+    """`choose_staged_slices` behind the same file cache as `sliced_plan` (``staged_<hash>.json``)."""
+    import hashlib
+    import json
+
+    shapes = [tuple(int(d) for d in sh) for sh in shapes]
+    cache_dir = cache_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans")
+    key = hashlib.sha1(json.dumps(["staged", einstr, shapes, int(min_slices), max_intermediate, sorted(kwargs.items())],
+                                  ensure_ascii=True).encode()).hexdigest()[:16]
+    fname = os.path.join(cache_dir, f"staged_{key}.json")
+    if os.path.exists(fname):
+        try:
+            with open(fname) as fh:
+                d = json.load(fh)
+            labels = tuple(d["labels"])
+            path = tuple(tuple(int(x) for x in p_) for p_ in d["path"])
+            lhs, out = einstr.split("->")
+            if (d.get("einsum_str") == einstr and all(lab in lhs and lab not in out for lab in labels)
+                    and len(path) == len(shapes) - 1):
+                return labels, path, d["report"]
+        except (OSError, ValueError, KeyError):
+            pass
+    labels, path, report = choose_staged_slices(einstr, shapes, min_slices=min_slices, max_intermediate=max_intermediate,
+                                                **kwargs)
+    try:
+        os.makedirs(cache_dir, exist_ok=True)
+        with open(fname, "w") as fh:
+            json.dump({"einsum_str": einstr, "shapes": shapes, "min_slices": int(min_slices),
+                       "max_intermediate": max_intermediate, "labels": list(labels),
+                       "path": [list(p_) for p_ in path], "report": report}, fh)
+    except OSError:
+        pass
+    return labels, path, report
+
+
+
+def _best_rank_grid(extents, world, dep_idx, stage_work):
+    """Factor ``world`` ranks over the sliced labels (``grid[i]`` ranks along label i, every factor at most the label's
+    extent) so that the work of the busiest rank is least: a stage costs a rank its work per evaluation times the
+    number of joint values of the stage's labels inside the rank's block."""
+    n = len(extents)
+    best = None
+
+    def blocks(e_, g_):
+        return -(-e_ // g_)          # the largest share of a range of e_ cut into g_ parts
+
+    def rec(i, left, grid):
+        nonlocal best
+        if i == n:
+            if left != 1:
+                return
+            cost = sum(w_ * int(np.prod([blocks(extents[j], grid[j]) for j in dep])) for dep, w_ in zip(dep_idx, stage_work))
+            key = (cost, tuple(-g_ for g_ in grid))      # ties: ranks along the leading labels first
+            if best is None or key < best[0]:
+                best = (key, tuple(grid))
+            return
+        for g_ in range(1, min(left, extents[i]) + 1):
+            if left % g_ == 0:
+                rec(i + 1, left // g_, grid + [g_])
+
+    rec(0, world, [])
+    if best is None:
+        raise ValueError(f"{world} ranks cannot be factored over sliced labels of extents {extents}")
+    return best[1]
+
+
+class StagedSlicedContraction:
+    """Index slicing in STAGES (`stage_decomposition`): every stage is one plan whose evaluations - one per joint
+    value of the sliced labels it depends on - run as replicas, lower stages first; their results stay on the device
+    as operands of the stages above (an evaluation is a pointer offset, like an input's slice), only the root stage
+    runs once per slice.  Everything is enqueued on ONE stream with no host wait in between; the scales of lower
+    stages are added to their consumers' on the device, the root's ``(T_hat_s, c_s)`` are summed by
+    `k_combine_split` and joined across ranks exactly like `SlicedContraction.run_small` (ONE ``all_gather``).
+
+    ``outer``: the first ``outer`` labels (in the order given) are walked in a host loop, one joint value - one GROUP
+    of slices - at a time, so that a stage only ever holds the evaluations one group needs (8 x 8 PEPS, D = 16: stage
+    results of 2^28 elements; all 256 evaluations of one would be 256 GiB).  A stage is recomputed for a group only
+    when the evaluations that group needs differ from the ones it holds (`paths.hoisted_profile(outer=...)` counts
+    exactly that).  ``None`` = the smallest count whose buffers fit ``held_budget`` bytes.
+
+    Ranks: the grid of label values is cut into one BLOCK per rank (`_best_rank_grid`: the factorisation of the
+    ranks over the labels under which the busiest rank has least to do); of a lower stage a rank evaluates what its
+    block projects onto (a stage that depends on no sliced label is computed by every rank - that work does not
+    scale, which is what ``parallel`` in `choose_staged_slices` prices).  Small results only (closed networks, a few thousand elements);
+    ``optimize`` must be an explicit linear path (the one the labels were chosen with)."""
+
+    def __init__(self, einstr, operands, slice_labels, optimize, rank=0, world=1, device=0, dtype=None,
+                 workspace_budget=64 << 30, min_saved=1 << 28, outer=None, held_budget=64 << 30):
+        import torch
+
+        from . import einsum as E
+
+        if isinstance(optimize, (str, bool)) or optimize is None:
+            raise ValueError("StagedSlicedContraction needs the explicit path its labels were chosen with")
+        self.rank, self.world, self.device = rank, world, device
+        self._args = (einstr, operands, tuple(slice_labels), _hashable(optimize), dtype, workspace_budget)
+        shapes = [tuple(np.shape(o)) for o in operands]
+        terms, out, sizes = paths.parse_einsum_input(einstr, shapes)
+        self.sizes, self.slice_labels = sizes, tuple(slice_labels)
+        self.np_dtype = np.dtype(dtype or np.result_type(*[np.asarray(o).dtype for o in operands]))
+        if self.np_dtype not in (np.float32, np.float64):
+            self.np_dtype = np.dtype(np.float64)
+        tdt = torch.float32 if self.np_dtype == np.float32 else torch.float64
+        item = self.np_dtype.itemsize
+        dev = torch.device("cuda", device)
+        self.out_shape = tuple(sizes[c] for c in out)
+        if int(np.prod(self.out_shape)) >= DEVICE_JOIN_MIN_NUMEL:
+            raise NotImplementedError("staged slicing joins small results only; use SlicedContraction for large open outputs")
+        self.stage_desc = stage_decomposition(einstr, shapes, self.slice_labels, optimize, min_saved=min_saved)
+        at = {lab: i for i, lab in enumerate(self.slice_labels)}
+        n_stage = len(self.stage_desc)
+        dep_idx = [[at[lab] for lab in st["dep"]] for st in self.stage_desc]
+        extents = [sizes[lab] for lab in self.slice_labels]
+        self.n_total = int(np.prod(extents)) if extents else 1
+        if self.n_total < world:
+            raise ValueError(f"{self.n_total} slices cannot be dealt to {world} ranks")
+        # which slices are this rank's: a BLOCK of the grid of label values - ranks factored over the labels, a
+        # contiguous share of every label's range - chosen so that the stages below the root are evaluated as few times
+        # as possible (a rank evaluates a stage once per value of the stage's labels that its slices touch: a 2 x 4
+        # block of an 8 x 8 grid touches 2 + 4 values of the two labels, a 1 x 8 row 1 + 8)
+        stage_work = []
+        for st in self.stage_desc:
+            lhs_ = st["einsum"].split("->")[0].split(",")
+            stage_work.append(paths.path_cost([set(t_) for t_ in lhs_], st["out"], sizes, st["path"])[0] if len(lhs_) > 1 else 0)
+        self.rank_grid = _best_rank_grid(extents, world, dep_idx, stage_work)
+        coords, rem = [], rank
+        for g_ in reversed(self.rank_grid):
+            coords.append(rem % g_)
+            rem //= g_
+        coords.reverse()
+        self.my_slices = list(itertools.product(*[shard_range(e_, c_, g_) for e_, c_, g_ in zip(extents, coords, self.rank_grid)]))
+        stage_numel, stage_stride = [], []
+        for st in self.stage_desc:
+            numel = int(np.prod([sizes[c] for c in st["out"]])) if st["out"] else 1
+            stage_numel.append(numel)
+            stage_stride.append((numel * item + 15) // 16 * 16 // item)     # evaluations start on 16-byte boundaries
+
+        def grouping(n_outer):
+            """Groups of this rank's slices by the values of the first n_outer labels, and per stage and group the
+            evaluations (tuples over the stage's own labels) the group needs, in order."""
+            groups = {}
+            for v in self.my_slices:
+                groups.setdefault(v[:n_outer], []).append(v)
+            order = list(groups)
+            need = [[sorted({tuple(v[i] for i in dep_idx[k]) for v in groups[g]}) for g in order] for k in range(n_stage)]
+            return [groups[g] for g in order], need
+
+        if outer is None:      # the fewest outer labels whose stage buffers fit the budget
+            for outer in range(len(self.slice_labels) + 1):
+                _g, need = grouping(outer)
+                held = sum(max(len(x) for x in need[k]) * stage_stride[k] * item for k in range(n_stage - 1))
+                if held <= held_budget:
+                    break
+        self.outer = int(outer)
+        groups, need = grouping(self.outer)
+        self.n_groups = len(groups)
+
+        self.tstream = torch.cuda.Stream(dev)
+        # inputs: sliced axes first (in slice_labels order), so a slice is one contiguous block at a pointer offset
+        self.tensors, lead_labels, blocks = [], [], []
+        for term, op in zip(terms, operands):
+            lead = sorted((i for i, c in enumerate(term) if c in self.slice_labels), key=lambda i: at[term[i]])
+            rest = [i for i, c in enumerate(term) if c not in self.slice_labels]
+            t = torch.as_tensor(np.ascontiguousarray(np.transpose(np.asarray(op, dtype=self.np_dtype), lead + rest)),
+                                device=dev, dtype=tdt)
+            self.tensors.append(t)
+            lead_labels.append(tuple(term[i] for i in lead))
+            blocks.append(int(np.prod([sizes[term[i]] for i in rest])) if rest else 1)
+        self._owned = {}
+
+        def input_ptr(i, values):
+            idx = 0
+            for lab in lead_labels[i]:
+                idx = idx * sizes[lab] + values[at[lab]]
+            p_ = self.tensors[i].data_ptr() + idx * blocks[i] * item
+            if p_ % 16:      # odd-sized block: an aligned copy of this slice
+                if (i, idx) not in self._owned:
+                    self._owned[(i, idx)] = self.tensors[i][tuple(values[at[lab]] for lab in lead_labels[i])].clone()
+                p_ = self._owned[(i, idx)].data_ptr()
+            return p_
+
+        # per stage: plan, executor, result buffer (as many evaluations as the largest group needs; the root: one per slice)
+        self.stages = []
+        n_local = len(self.my_slices)
+        for k, st in enumerate(self.stage_desc):
+            root = k == n_stage - 1
+            n_buf = n_local if root else max(len(x) for x in need[k])
+            lhs = st["einsum"].split("->")[0].split(",")
+            st_shapes = [tuple(sizes[c] for c in t_) for t_ in lhs]
+            probe = E._native_plan(E._contract_path(st["einsum"], tuple(st_shapes), optimize=_hashable(st["path"]),
+                                                    memory_limit=None, use_blas=True), tuple(st_shapes), self.np_dtype.name)
+            per = max(1, probe.workspace_bytes(2) - probe.workspace_bytes(1))
+            R = int(max(1, min(max(len(x) for x in need[k]), workspace_budget // per)))
+            bc = E.BatchedContraction(st["einsum"], st_shapes, self.np_dtype, optimize=st["path"], replicas=R, device=device,
+                                      stream=self.tstream.cuda_stream)
+            self.stages.append({
+                "desc": st, "bc": bc, "R": R, "numel": stage_numel[k], "stride": stage_stride[k],
+                "out": torch.zeros((n_buf, stage_stride[k]), device=dev, dtype=tdt),
+                "scratch": torch.zeros((R, stage_stride[k]), device=dev, dtype=tdt),
+                "c": torch.zeros(n_buf, dtype=torch.float64, device=dev),
+                "cum": torch.zeros(n_buf, dtype=torch.float64, device=dev),
+                "launches": 0, "evaluated": 0})
+
+        # the schedule: group by group, every stage whose needed evaluations changed is recomputed into its buffer
+        self.schedule = []
+        holds = [None] * n_stage                     # evaluations currently in each stage's buffer, in slot order
+        done = 0                                     # root slices scheduled so far (= their slot in the root buffer)
+        for g, slices in enumerate(groups):
+            for k, st in enumerate(self.stage_desc):
+                S = self.stages[k]
+                root = k == n_stage - 1
+                want = need[k][g]
+                if not root and holds[k] == want:
+                    continue
+                holds[k] = want
+                slot0 = done if root else 0
+                pos_child = {j: {e: q for q, e in enumerate(holds[j])} for kind, j in st["operands"] if kind == "st"}
+                proj = {j: [st["dep"].index(lab) for lab in self.stage_desc[j]["dep"]] for j in pos_child}
+
+                def eval_ptrs(e, st=st, k=k, pos_child=pos_child, proj=proj):
+                    full = [0] * len(self.slice_labels)
+                    for i, v in zip(dep_idx[k], e):
+                        full[i] = v
+                    ptrs = []
+                    for kind, j in st["operands"]:
+                        if kind == "in":
+                            ptrs.append(input_ptr(j, full))
+                        else:
+                            q = pos_child[j][tuple(e[i] for i in proj[j])]
+                            ptrs.append(self.stages[j]["out"].data_ptr() + q * self.stages[j]["stride"] * item)
+                    return ptrs
+
+                R, n_steps = S["R"], S["bc"].plan.n_steps
+                for c0 in range(0, len(want), R):
+                    chunk = want[c0:c0 + R]
+                    n = len(chunk)
+                    padded = chunk + [chunk[-1]] * (R - n)
+                    in_ptrs = [p_ for e in padded for p_ in eval_ptrs(e)]
+                    out_ptrs = [S["out"].data_ptr() + (slot0 + c0 + r) * S["stride"] * item if r < n
+                                else S["scratch"].data_ptr() + r * S["stride"] * item for r in range(R)]
+                    resc = torch.empty(n * n_steps, dtype=torch.float64).pin_memory()
+                    self.schedule.append(("launch", k, S["bc"].executor.make_enqueue(in_ptrs, out_ptrs), slot0 + c0, n, resc))
+                    S["launches"] += 1
+                    S["evaluated"] += n
+                # scales of the stages below ride along with their results: cum = own + sum of the children's
+                kids_idx = [(j, torch.as_tensor([pos_child[j][tuple(e[i] for i in proj[j])] for e in want], dtype=torch.int64, device=dev))
+                            for j in pos_child]
+                self.schedule.append(("cum", k, slot0, len(want), kids_idx))
+            done += len(slices)
+        root = self.stages[-1]
+        numel = max(1, int(np.prod(self.out_shape)))
+        assert root["numel"] == numel and done == n_local
+        self.R = root["R"]
+        self._join = {"numel": numel, "packed": torch.zeros(numel + 1, dtype=torch.float64, device=dev),
+                      "gathered": torch.zeros(world * (numel + 1), dtype=torch.float64, device=dev),
+                      "final": torch.zeros(numel + 1, dtype=torch.float64, device=dev)}
+        self._plain = None
+        torch.cuda.synchronize(dev)       # uploads, clones and zero fills ran on torch's current stream
+
+    def stage_list(self):
+        """``[(BatchedContraction, evaluations on this rank per contraction, replicas per launch, launches)]``."""
+        return [(S["bc"], S["evaluated"], S["R"], S["launches"]) for S in self.stages]
+
+    def slices_host(self):
+        """``(T_hat [n_local, ...], c [n_local])`` of this rank's slices as the LAST run left them on the device (the
+        root stage's results with the scales of the stages below added) - for slice-by-slice checks."""
+        root = self.stages[-1]
+        self.tstream.synchronize()
+        t = root["out"][:, :root["numel"]].cpu().numpy().reshape((len(self.my_slices),) + self.out_shape)
+        return t, root["cum"].cpu().numpy()
+
+    def evaluations(self):
+        """Per stage: (labels it depends on, evaluations on this rank per contraction, this rank's slices = what plain
+        slicing would evaluate)."""
+        return [(S["desc"]["dep"], S["evaluated"], len(self.my_slices)) for S in self.stages]
+
+    def run(self, group=None):
+        """One sliced contraction; returns ``(T_hat [numpy], c)`` on every rank."""
+        import torch
+
+        dev = torch.device("cuda", self.device)
+        J = self._join
+        root = self.stages[-1]
+        ex = root["bc"].executor
+        with torch.cuda.stream(self.tstream):
+            for entry in self.schedule:
+                if entry[0] == "launch":
+                    _tag, k, launch, slot, n, resc = entry
+                    S = self.stages[k]
+                    launch()
+                    S["bc"].executor.snapshot_scales(S["c"].data_ptr() + 8 * slot, n, resc.data_ptr())
+                else:
+                    _tag, k, slot0, n, kids_idx = entry
+                    S = self.stages[k]
+                    cum = S["c"][slot0:slot0 + n]
+                    for j, idx in kids_idx:
+                        cum = cum + self.stages[j]["cum"].index_select(0, idx)
+                    S["cum"][slot0:slot0 + n] = cum
+            ex.combine_split(root["out"].data_ptr(), root["stride"], root["cum"].data_ptr(), 1, len(self.my_slices),
+                             J["numel"], J["packed"].data_ptr())
+        self.tstream.synchronize()
+        suspect = any(self.stages[e[1]]["bc"].executor.scales_suspect(e[5].data_ptr(), e[4]) for e in self.schedule if e[0] == "launch")
+        if suspect:
+            # a lazily rescaled product left the dtype's range somewhere: the whole contraction again on the plain,
+            # checked path (per-slice fetch repeats such a group with eager rescaling); every rank still joins once
+            if self._plain is None:
+                einstr, operands, labels, path, dtype, budget = self._args
+                self._plain = SlicedContraction(einstr, operands, labels, optimize=path, rank=self.rank, world=self.world,
+                                                device=self.device, dtype=dtype, workspace_budget=budget)
+            t_loc, c_loc = self._plain.local_result()
+            host = np.concatenate([np.asarray(t_loc, dtype=np.float64).ravel(), [float(c_loc)]])
+            J["packed"].copy_(torch.from_numpy(host))
+            torch.cuda.current_stream(dev).synchronize()
+        host = join_packed(ex, J, self.world, group, dev)
+        numel = J["numel"]
+        return host[:numel].reshape(self.out_shape).astype(self.np_dtype), np.asarray(host[numel], dtype=np.float64)
 
 
 DEVICE_JOIN_MIN_NUMEL = 1 << 14     # results at least this large are joined on the device (reduce-scatter + all-gather)

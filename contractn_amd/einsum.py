@@ -294,18 +294,19 @@ def parse_backend(arrays, backend="auto"):
 
 
 def _common_dtype(operands, backend, requested=None):
+    """The engine's arithmetic type for these operands: float32 or float64 (ints and bools compute in
+    float64); complex operands compute in the real type of their components (`_core_contract_complex`)."""
     if requested is not None:
         dt = np.dtype(requested)
     elif backend == "torch":
         import torch
 
-        dt = np.dtype(np.float64 if any(o.dtype == torch.float64 for o in operands) else np.float32)
-        if any(o.dtype.is_complex for o in operands):
-            raise NotImplementedError("complex tensors are not supported by the HIP engine")
+        wide = (torch.float64, torch.complex128)
+        dt = np.dtype(np.float64 if any(o.dtype in wide for o in operands) else np.float32)
     else:
         dt = np.result_type(*[np.asarray(o).dtype for o in operands])
     if dt.kind == "c":
-        raise NotImplementedError("complex tensors are not supported by the HIP engine")
+        dt = np.dtype(np.float32 if dt == np.complex64 else np.float64)
     if dt == np.float32:
         return np.dtype(np.float32)
     if dt.kind == "f" and dt.itemsize < 4:
@@ -325,6 +326,8 @@ def _core_contract(operands, contract_list, backend="numpy", **einsum_kwargs):
     )
     dtype = _common_dtype(operands, backend, einsum_kwargs.get("dtype"))
     shapes = tuple(tuple(int(d) for d in op.shape) for op in operands)
+    if _is_complex(operands, backend):
+        return _core_contract_complex(operands, contract_list, shapes, dtype, backend)
     plan = _native_plan(contract_list, shapes, dtype.name)
     if backend == "torch":
         return _run_torch(plan, operands, dtype)
@@ -333,6 +336,154 @@ def _core_contract(operands, contract_list, backend="numpy", **einsum_kwargs):
         outs, _dev_log, resc = ex.run_host([operands])
     log_scale = accumulate_log_scale(resc[0], dtype)
     return outs[0], log_scale
+
+
+# ---------------------------------------------------------------------------
+# complex tensors: the same engine on their (re, im) components
+# ---------------------------------------------------------------------------
+def _is_complex(operands, backend):
+    if backend == "torch":
+        return any(o.dtype.is_complex for o in operands)
+    return any(np.asarray(o).dtype.kind == "c" for o in operands)
+
+
+_COMPLEX_LABEL = 1 << 24          # integer labels of the (re, im) legs start here (symbols are code points < 2^21)
+# z = x * y on components: z_c = sum_ab S[a, b, c] x_a y_b
+_CSTRUCT = np.zeros((2, 2, 2))
+_CSTRUCT[0, 0, 0], _CSTRUCT[1, 1, 0], _CSTRUCT[0, 1, 1], _CSTRUCT[1, 0, 1] = 1.0, -1.0, 1.0, 1.0
+
+
+@lru_cache(maxsize=64)
+def _complex_plan_cached(contract_list, shapes, is_cplx, dtype_name):
+    """The native plan of a network with complex operands, on REAL tensors: a complex operand is its array of
+    (re, im) pairs - one more, innermost axis of extent 2 with a label of its own - and a pairwise step on two complex
+    tensors ``z = x y`` is ``z_c = sum_ab S_abc x_a y_b`` with the 2 x 2 x 2 structure tensor S of complex
+    multiplication: S is contracted into the smaller operand (a streaming step that doubles it: the 2 x 2 real matrix
+    of every element), then ONE real GEMM with the pair leg as one more contracted label does the step.  A real operand
+    meeting a complex one needs nothing (the pair leg rides along as a free label).  The reference reaches complex
+    arithmetic through NumPy (einsum.py:371-384; SURVEY.md App. A row complex128); here it is four real multiply-adds per
+    complex one on the same kernels.  Returns ``(plan, S inputs appended, result is complex)``."""
+    n = len(shapes)
+    in_labels, steps = lower_contraction_list(n, contract_list, shapes)
+    sizes = {}
+    for lab, shp in zip(in_labels, shapes):
+        for l_, d_ in zip(lab, shp):
+            sizes[l_] = int(d_)
+    fresh = [_COMPLEX_LABEL]
+
+    def new_label():
+        fresh[0] += 1
+        return fresh[0]
+
+    cplx = {}                                   # SSA id -> label of its (re, im) leg
+    labels_of = {}
+    new_in_labels, new_shapes = [], []
+    for i in range(n):
+        lab = tuple(in_labels[i])
+        shp = tuple(shapes[i])
+        if is_cplx[i]:
+            cplx[i] = new_label()
+            lab, shp = lab + (cplx[i],), shp + (2,)
+        labels_of[i] = lab
+        new_in_labels.append(lab)
+        new_shapes.append(shp)
+    # first pass: how many S operands are needed (they are appended to the inputs, so ids shift by their count)
+    n_s = 0
+    probe = dict(cplx)
+    for k, (lhs, rhs, _out) in enumerate(steps):
+        both = rhs >= 0 and lhs in probe and rhs in probe
+        n_s += 1 if both else 0
+        if lhs in probe or (rhs >= 0 and rhs in probe):
+            probe[n + k] = True
+    n_in = n + n_s
+    remap = {i: i for i in range(n)}             # old SSA id -> new SSA id
+    new_steps, s_used = [], 0
+
+    def numel(lab):
+        v = 1
+        for l_ in lab:
+            v *= sizes.get(l_, 2)
+        return v
+
+    for k, (lhs, rhs, out) in enumerate(steps):
+        out = tuple(out)
+        a, b = remap[lhs], (remap[rhs] if rhs >= 0 else -1)
+        ca, cb = cplx.get(lhs), (cplx.get(rhs) if rhs >= 0 else None)
+        if ca is not None and cb is not None:
+            xo = new_label()
+            s_id = n + s_used
+            s_used += 1
+            small_is_lhs = numel(labels_of[lhs]) <= numel(labels_of[rhs])
+            x_small, x_big = (ca, cb) if small_is_lhs else (cb, ca)
+            small, big = (a, b) if small_is_lhs else (b, a)
+            small_lab = labels_of[lhs] if small_is_lhs else labels_of[rhs]
+            new_in_labels.append((ca, cb, xo))
+            new_shapes.append((2, 2, 2))
+            widened = tuple(l_ for l_ in small_lab if l_ != x_small) + (x_big, xo)
+            new_steps.append((small, s_id, widened))                     # the element's 2 x 2 real matrix
+            mid = n_in + len(new_steps) - 1
+            first, second = (mid, big) if small_is_lhs else (big, mid)   # keep the step's left / right operands
+            new_steps.append((first, second, out + (xo,)))
+            cplx[n + k] = xo
+        elif ca is not None or cb is not None:
+            x = ca if ca is not None else cb
+            new_steps.append((a, b, out + (x,)))
+            cplx[n + k] = x
+        else:
+            new_steps.append((a, b, out))
+        labels_of[n + k] = out + ((cplx[n + k],) if n + k in cplx else ())
+        remap[n + k] = n_in + len(new_steps) - 1
+    plan = engine.Plan(dtype_name, new_in_labels, new_shapes, new_steps, stabilize=True, min_norm=MIN_NORM)
+    return plan, n_s, (n + len(steps) - 1) in cplx
+
+
+def _core_contract_complex(operands, contract_list, shapes, dtype, backend):
+    """`_core_contract` for networks with complex operands (see `_complex_plan_cached`).  The engine normalises by the
+    mean of |re| + |im|; the reference by the mean modulus (einsum.py:97 ``abs``): the final tensor is brought to the
+    reference's normalisation here - one pass over the result - and the register moves by the log of the ratio."""
+    if backend == "torch":
+        import torch
+
+        is_c = tuple(bool(o.dtype.is_complex) for o in operands)
+    else:
+        operands = [np.asarray(o) for o in operands]
+        is_c = tuple(o.dtype.kind == "c" for o in operands)
+    with _PLAN_LOCK:
+        plan, n_s, out_complex = _complex_plan_cached(contract_list, shapes, is_c, dtype.name)
+    cdt = np.dtype(np.complex64 if dtype == np.float32 else np.complex128)
+    if backend == "torch":
+        tdt = torch.float32 if dtype == np.float32 else torch.float64
+        ctd = torch.complex64 if dtype == np.float32 else torch.complex128
+        dev = next((o.device for o in operands if o.is_cuda), torch.device("cpu"))
+        host = []
+        for o, c in zip(operands, is_c):
+            o = o.detach()
+            o = torch.view_as_real(o.to(ctd).contiguous()) if c else o.to(tdt)
+            host.append(o.cpu().numpy())
+    else:
+        host = []
+        for o, c in zip(operands, is_c):
+            if c:
+                o = np.ascontiguousarray(o, dtype=cdt)
+                host.append(o.view(dtype).reshape(o.shape + (2,)))
+            else:
+                host.append(np.ascontiguousarray(o, dtype=dtype))
+    host += [_CSTRUCT.astype(dtype)] * n_s
+    ex = _executor_for(plan, 1)
+    with ex.lock:
+        outs, _dev_log, resc = ex.run_host([host])
+    log_scale = accumulate_log_scale(resc[0], dtype, register_dtype=dtype if backend == "torch" else np.float64)
+    res = outs[0]
+    if out_complex:
+        res = np.ascontiguousarray(res).view(cdt).reshape(res.shape[:-1])
+        norm = np.sum(np.abs(res))               # the reference's norm: moduli (einsum.py:97)
+        if norm > MIN_NORM:
+            ratio = (norm / res.size).astype(dtype) if hasattr(norm, "astype") else dtype.type(norm / res.size)
+            res = (res / ratio).astype(cdt)
+            log_scale = np.asarray(log_scale + np.log(ratio).astype(log_scale.dtype), dtype=log_scale.dtype)
+    if backend == "torch":
+        return torch.from_numpy(np.array(res)).to(dev), torch.tensor(float(log_scale), dtype=tdt, device=dev)
+    return res, log_scale
 
 
 def _run_torch(plan, operands, dtype):

@@ -192,30 +192,64 @@ def hoisted_cost(term_sets, out, sizes, path, slice_labels, parallel=1):
     charged ``parallel`` evaluations - the first figure is then ``parallel`` x the modelled time of one rank, and
     a slicing whose sliced labels sit in a corner of the network (nearly everything slice-independent: no overhead,
     no parallelism either) stops looking free."""
+    return hoisted_profile(term_sets, out, sizes, path, slice_labels, parallel)[:3]
+
+
+def hoisted_profile(term_sets, out, sizes, path, slice_labels, parallel=1, outer=0):
+    """`hoisted_cost` plus a fourth figure: the elements held between STAGES - every intermediate whose consumer
+    depends on more sliced labels than it does is kept for all its evaluations until the consumers have run
+    (`dist.StagedSlicedContraction` materialises those), so ``sum evaluations x sliced size`` over them bounds
+    that executor's extra memory.
+
+    ``outer`` = how many of the LEADING sliced labels the executor walks in a host loop (lexicographic, the first
+    label outermost) instead of materialising all their values at once: what is held shrinks to one value of those
+    labels at a time, and a node is re-evaluated whenever a label at or before the LAST outer label it depends on
+    moves - a node below outer label 2 but not below label 1 is computed again for every value of label 1 - so the
+    evaluation count of a dependency set D becomes ``prod(extent of D's inner labels) x prod(extent of outer labels
+    up to the last one in D)``."""
     sl = list(slice_labels)
     sz = dict(sizes)
     for lab in sl:
         sz[lab] = 1
-    live = [(set(t), sum(1 << b for b, lab in enumerate(sl) if lab in t)) for t in term_sets]
-    total, biggest, one = 0, 0, 0
+    cache = {}
+
+    def evaluations(bits):
+        """(evaluations over the whole contraction, evaluations alive at once)"""
+        if bits not in cache:
+            last_outer = -1
+            for bit in range(min(outer, len(sl))):
+                if bits >> bit & 1:
+                    last_outer = bit
+            total_, alive = 1, 1
+            for bit, lab in enumerate(sl):
+                if bit < outer:
+                    if bit <= last_outer:
+                        total_ *= sizes[lab]
+                elif bits >> bit & 1:
+                    total_ *= sizes[lab]
+                    alive *= sizes[lab]
+            cache[bits] = (total_, alive)
+        return cache[bits]
+
+    live = [(set(t), sum(1 << b for b, lab in enumerate(sl) if lab in t), True) for t in term_sets]
+    total, biggest, one, held = 0, 0, 0, 0
     for step in path:
         step = tuple(sorted(step))
         if len(step) == 1:
             continue
         i, j = step
-        (a, da), (b, db) = live[i], live[j]
+        (a, da, leaf_a), (b, db, leaf_b) = live[i], live[j]
         rest = [x for k, x in enumerate(live) if k not in (i, j)]
         new, _ = _pair_result(a, b, [x[0] for x in rest], out)
-        times = 1
-        for bit, lab in enumerate(sl):
-            if (da | db) >> bit & 1:
-                times *= sizes[lab]
         c = _size(a | b, sz)
-        total += c * max(times, parallel)
+        total += c * max(evaluations(da | db)[0], parallel)
         one += c
         biggest = max(biggest, _size(new, sz))
-        live = rest + [(new, da | db)]
-    return total, biggest, one
+        for lab_set, d, leaf in ((a, da, leaf_a), (b, db, leaf_b)):
+            if not leaf and d != (da | db):
+                held += evaluations(d)[1] * _size(lab_set, sz)
+        live = rest + [(new, da | db, False)]
+    return total, biggest, one, held
 
 
 def path_time_model(term_sets, out, sizes, path, elem_bytes=4):

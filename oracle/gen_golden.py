@@ -153,6 +153,30 @@ def main():
         tn, ssa = nets.mps_overlap(TN, 4, 32, 4, dtype=np.float32, seed=3, scale=1.0 / mag)
         save(f"mps_overlap_4x32x4_f32_{tag}", tn, ssa_to_linear(ssa, 8), note=f"zipper path; entries ~ {mag:g}")
 
+    # -- complex tensors (the reference contracts them through NumPy: modulus norm, real register)
+    def complexify(tn, seed, cdtype, every=1):
+        rng_c = np.random.default_rng(seed)
+        for k, node in enumerate(tn.nodes(as_iter=True, copy_nodes=False, danglers=False)):
+            if k % every == 0:
+                t = np.asarray(node.tensor)
+                node.tensor = (t + 1j * rng_c.standard_normal(t.shape) * np.mean(np.abs(t))).astype(cdtype)
+
+    tn, ssa = nets.mps_overlap(TN, 5, 12, 3, dtype=np.float64, seed=8)
+    complexify(tn, 80, np.complex128)
+    save("mps_overlap_5x12x3_c128", tn, ssa_to_linear(ssa, 10), note="zipper path; complex128 cores")
+    tn, ssa = nets.mps_overlap(TN, 4, 40, 4, dtype=np.float32, seed=9)
+    complexify(tn, 81, np.complex64)
+    save("mps_overlap_4x40x4_c64", tn, ssa_to_linear(ssa, 8), note="zipper path; complex64 cores, MFMA-sized steps")
+    tn, ssa = nets.mps_overlap(TN, 4, 10, 3, dtype=np.float64, seed=10)
+    complexify(tn, 82, np.complex128, every=2)
+    save("mps_overlap_4x10x3_mixed_c128", tn, ssa_to_linear(ssa, 8), note="zipper path; every second core complex, the rest real")
+    tn = nets.mps_open(TN, (3, 5, 4), (2, 3, 2, 4), dtype=np.float64, seed=12)
+    complexify(tn, 83, np.complex128)
+    save("mps_open_random_c128", tn, own_path(tn.einsum_str, [p.shape for p in tn.params]), note="open legs, complex128")
+    tn = nets.cp_network(TN, 5, (6, 7, 8), dtype=np.float64, seed=13)
+    complexify(tn, 84, np.complex128)
+    save("cp_r5_c128", tn, own_path(tn.einsum_str, [p.shape for p in tn.params]), note="ac,ad,ae->cde, complex128: hyperedge")
+
     # -- open MPS, random and all-ones (reference tests/test_einsum.py:28-64)
     tn = nets.mps_open(TN, (3, 5, 4), (2, 3, 2, 4), dtype=np.float64, seed=11)
     ein = tn.einsum_str

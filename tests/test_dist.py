@@ -361,3 +361,83 @@ def test_batch_sharding_with_more_ranks_than_items_raises_on_every_rank():
     for rank in range(4):
         with pytest.raises(ValueError):
             D.contract_batch_sharded("bk,k->b", ops, "b", contract_fn=oracle_contract, rank=rank, world=4)
+
+
+def _ascii(eq):
+    table, res = {}, []
+    for ch in eq:
+        if ch in ",->":
+            res.append(ch)
+        else:
+            table.setdefault(ch, "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ"[len(table)])
+            res.append(table[ch])
+    return "".join(res)
+
+
+@pytest.mark.parametrize("min_saved", [0, 1 << 10, 1 << 60])
+def test_stage_decomposition_evaluates_every_stage_once_per_value_of_its_labels(min_saved):
+    """`dist.stage_decomposition` emulated with NumPy: every stage is evaluated once per joint value of the sliced
+    labels IT depends on (cached here by exactly that key), the root once per slice, and the slices' sum equals the
+    unsliced contraction.  ``min_saved = 0`` hoists every slice-independent subtree, a huge value none (one stage =
+    plain slicing); the count of evaluations shrinks accordingly."""
+    import itertools
+
+    from contractn_amd import TN, paths
+    from tests import networks as nets
+
+    tn = nets.peps_closed(TN, 4, 4, 3, dtype=np.float64, seed=6)
+    ops = list(tn.params)
+    shapes = [o.shape for o in ops]
+    labels, path, rep = D.choose_staged_slices(tn.einsum_str, shapes, min_slices=9, seeds=2)
+    assert rep["slices"] >= 9 and rep["staged"] and rep["work_overhead"] <= rep["plain_overhead"]
+    terms, _out, sizes = paths.parse_einsum_input(tn.einsum_str, shapes)
+    stages = D.stage_decomposition(tn.einsum_str, shapes, labels, path, min_saved=min_saved)
+    assert stages[-1]["dep"] == tuple(labels) and stages[-1]["out"] == ""
+    cache = [dict() for _ in stages]
+
+    def evaluate(k, assign):
+        st = stages[k]
+        key = tuple(assign[lab] for lab in st["dep"])
+        if key not in cache[k]:
+            arrs = []
+            for kind, i in st["operands"]:
+                if kind == "in":
+                    arrs.append(ops[i][tuple(assign[lab] if lab in labels else slice(None) for lab in terms[i])])
+                else:
+                    assert i < k and set(stages[i]["dep"]) < set(st["dep"])      # lower stages first, fewer labels
+                    arrs.append(evaluate(i, assign))
+            clist = cpu_ref.contraction_list(st["einsum"], [a.shape for a in arrs], st["path"])
+            t, c, _ = cpu_ref.core_contract(arrs, clist)
+            cache[k][key] = np.asarray(t) * np.exp(float(c))
+        return cache[k][key]
+
+    total = 0.0
+    for vals in itertools.product(*[range(sizes[lab]) for lab in labels]):
+        total = total + evaluate(len(stages) - 1, dict(zip(labels, vals)))
+    ref = np.einsum(_ascii(tn.einsum_str), *ops, optimize=True)
+    assert abs(float(total) - float(ref)) <= 1e-10 * abs(float(ref))
+    evals = sum(len(c) for c in cache)
+    if min_saved == 0:
+        assert len(stages) > 1 and any(st["dep"] == () for st in stages)
+        assert all(len(c) == int(np.prod([sizes[lab] for lab in st["dep"]])) for c, st in zip(cache, stages))
+    if min_saved == 1 << 60:
+        assert len(stages) == 1 and evals == rep["slices"]
+
+
+def test_hoisted_cost_counts_evaluations_per_dependency_set():
+    """`paths.hoisted_cost`: a label contracted at the root slices for free; slicing a label of a corner repeats
+    nothing either but leaves nothing to share out, which ``parallel`` charges for."""
+    from contractn_amd import paths
+
+    #   a - b - c      chain ab,bc,cd,de: contract (ab,bc) and (cd,de) first, then the halves over c
+    terms = ["ab", "bc", "cd", "de"]
+    sizes = {"a": 4, "b": 8, "c": 16, "d": 8, "e": 4}
+    sets = [set(t) for t in terms]
+    path = [(0, 1), (0, 1), (0, 1)]            # (ab,bc)->ac ; (cd,de)->ce ; (ac,ce)->ae
+    base, _big = paths.path_cost(sets, "ae", sizes, path)
+    tot, big, one = paths.hoisted_cost(sets, "ae", sizes, path, ["c"])
+    assert tot == base and one * 16 == base          # c is summed at the root: every node carries it, no overhead
+    tot_b, _b, one_b = paths.hoisted_cost(sets, "ae", sizes, path, ["b"])
+    # b lives in the left half only: the right half (cd,de) is evaluated once, the rest 8 times at 1/8 of the size
+    assert tot_b < one_b * 8 and tot_b == base + (8 - 1) * 4 * 16 * 4
+    assert paths.hoisted_cost(sets, "ae", sizes, path, ["b"], parallel=8)[0] == one_b * 8

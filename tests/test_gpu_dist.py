@@ -398,3 +398,61 @@ def test_device_join_equals_host_join_also_for_a_tiny_slice(monkeypatch):
     np.testing.assert_allclose(np.asarray(t2, dtype=np.float64) * np.exp(float(c2)), ref, rtol=1e-5)
     t3, c3 = sc2.local_result_device()
     np.testing.assert_allclose(t3.cpu().numpy().astype(np.float64) * np.exp(float(c3)), ref, rtol=1e-5)
+
+
+def test_staged_slicing_equals_plain_slicing_and_the_unsliced_value():
+    """`StagedSlicedContraction`: slice-independent parts of the tree are contracted once, parts below one sliced
+    label once per value of it, only the root stage once per slice - same value as plain slicing (every slice
+    repeats everything) and as the unsliced network, slice by slice; fewer evaluations than plain slicing; two
+    emulated ranks partition the root's slices and evaluate only what those project onto."""
+    from contractn_amd import TN, dist
+    from contractn_amd.paths import ssa_to_linear
+    from tests import networks as nets
+
+    rows = cols = 5
+    tn = nets.peps_closed(TN, rows, cols, 4, dtype=np.float32, seed=6)
+    ops = list(tn.params)
+    shapes = [o.shape for o in ops]
+    row = ssa_to_linear(nets.peps_row_path(rows, cols), 2 * rows * cols)
+    t_u, c_u = tn.contract(optimize=row, split_format=True)
+    labels, path, rep = dist.choose_staged_slices(tn.einsum_str, shapes, min_slices=16, seeds=2)
+    assert rep["slices"] >= 16 and rep["work_overhead"] < rep["plain_overhead"]
+    st = dist.StagedSlicedContraction(tn.einsum_str, ops, labels, optimize=path, min_saved=1 << 12)
+    assert len(st.stages) > 1
+    ev = st.evaluations()
+    assert ev[-1][1] == rep["slices"] and any(n < rep["slices"] for _dep, n, _all in ev[:-1])
+    for _ in range(4):                                   # eager launches, graph capture, replays: the same bits
+        t_s, c_s = st.run()
+        assert float(t_s) == float(t_u) and abs(float(c_s) - float(c_u)) <= 1e-3
+    plain = dist.SlicedContraction(tn.einsum_str, ops, labels, optimize=path)
+    t_p, c_p = plain.run()
+    assert float(t_p) == float(t_s) and abs(float(c_p) - float(c_s)) <= 2e-5
+    pt, pc = plain.slices_host()
+    gt, gc = st.slices_host()
+    assert np.array_equal(pt.ravel(), gt.ravel()) and np.max(np.abs(pc - gc)) <= 2e-5     # slice by slice
+    # a tiny workspace budget: one evaluation per launch, several launches per stage
+    small = dist.StagedSlicedContraction(tn.einsum_str, ops, labels, optimize=path, min_saved=1 << 12, workspace_budget=1)
+    assert small.R == 1
+    t_k, c_k = small.run()
+    assert float(t_k) == float(t_s) and abs(float(c_k) - float(c_s)) <= 1e-6
+    # the leading labels walked in a host loop (stage buffers hold one group's evaluations at a time; stages are
+    # recomputed when the group needs other evaluations than the ones held): same value, never fewer evaluations
+    for outer in range(1, len(labels) + 1):
+        looped = dist.StagedSlicedContraction(tn.einsum_str, ops, labels, optimize=path, min_saved=1 << 12, outer=outer)
+        assert looped.outer == outer and looped.n_groups > 1
+        for _ in range(3):
+            t_o, c_o = looped.run()
+            assert float(t_o) == float(t_s) and abs(float(c_o) - float(c_s)) <= 1e-6
+        assert all(a[1] >= b[1] for a, b in zip(looped.evaluations(), ev))
+        assert max(S["out"].shape[0] for S in looped.stages[:-1]) <= max(S["out"].shape[0] for S in st.stages[:-1])
+    tight = dist.StagedSlicedContraction(tn.einsum_str, ops, labels, optimize=path, min_saved=1 << 12, held_budget=1)
+    assert tight.outer == len(labels)                  # nothing fits: every label walked on the host
+    # two emulated ranks: disjoint halves of the slices, lower stages only where their slices need them
+    parts = []
+    for rank in range(2):
+        half = dist.StagedSlicedContraction(tn.einsum_str, ops, labels, optimize=path, rank=rank, world=2, min_saved=1 << 12)
+        assert len(half.my_slices) * 2 == rep["slices"]
+        half.world = 1                                   # no process group here: the local part only
+        parts.append(half.run())
+    t_j, c_j = dist.combine_split(parts)
+    assert float(t_j) == float(t_s) and abs(float(c_j) - float(c_s)) <= 1e-5

@@ -34,7 +34,7 @@ def test_golden_split(name):
     ops = g["operands"]
     t_hat, log_scale = contract(g["einsum_str"], *ops, optimize=g["path"], split_format=True)
     dt = np.result_type(*[o.dtype for o in ops])
-    dt = np.dtype(np.float32) if dt == np.float32 else np.dtype(np.float64)
+    dt = np.dtype(np.float32) if dt in (np.float32, np.complex64) else np.dtype(np.float64)   # (complex: its components' type)
     assert t_hat.shape == g["t_hat"].shape
     assert t_hat.dtype == g["t_hat"].dtype
     assert isinstance(log_scale, np.ndarray) and log_scale.shape == () and log_scale.dtype == np.float64
@@ -1042,3 +1042,95 @@ def test_nary_steps_and_optimize_false():
             got = np.asarray(t, dtype=np.float64) * np.exp(float(c))
             assert rel_err(got, ref) <= tol, (ein, np.dtype(dtype).name)
             assert abs(np.mean(np.abs(t)) - 1.0) < 1e-5
+
+
+# ---- the one-tile-per-CU form (k_mfma_f32_h): 128 x 128 tiles, K split over the two halves of an 8-wave workgroup ---------
+@pytest.fixture
+def force_h_form(monkeypatch):
+    """The launcher takes this form when a step is about one 128 x 128 tile per CU; these tests force it for every
+    eligible step (operands in 16-byte-request modes, K a multiple of 32)."""
+    monkeypatch.setenv("CTN_H", "1")
+    E.clear_caches()
+    yield
+    E.clear_caches()
+
+
+@pytest.mark.parametrize("einstr,shapes,path", [
+    ("km,kn,nj->mj", [(64, 128), (64, 128), (128, 8)], ((0, 1), (0, 1))),        # one tile, two k-tiles per K half
+    ("km,kn,nj->mj", [(96, 384), (96, 256), (256, 8)], ((0, 1), (0, 1))),        # 3 x 2 tiles, three k-tiles per half
+    ("km,kn,nj->mj", [(544, 128), (544, 128), (128, 8)], ((0, 1), (0, 1))),      # 17 k-tiles per half: the ring wraps
+    ("xkm,xkn,xnj->xmj", [(3, 64, 128), (3, 64, 128), (3, 128, 4)], ((0, 1), (0, 1))),   # batch (hyperedge) label
+    ("km,kn,nj->mj", [(64, 200), (64, 100), (100, 8)], ((0, 1), (0, 1))),        # ragged M and N: masked edge tiles
+    ("mk,kn,nj->mj", [(256, 64), (64, 128), (128, 8)], ((0, 1), (0, 1))),        # row-major A: requests along k
+    ("km,nk,nj->mj", [(96, 256), (384, 96), (384, 8)], ((0, 1), (0, 1))),        # k-contiguous B
+    ("mk,nk,nj->mj", [(200, 128), (100, 128), (100, 8)], ((0, 1), (0, 1))),      # both, ragged M and N
+    ("km,kn,nj,mj->", [(64, 256), (64, 256), (256, 16), (256, 16)], ((0, 1), (0, 1), (0, 1))),  # feeds rescaled intermediates on
+])
+def test_h_form_kernel_vs_numpy(einstr, shapes, path, force_h_form):
+    rng = np.random.default_rng(17)
+    ops = [(rng.standard_normal(s) * rng.uniform(0.5, 3.0)).astype(np.float32) for s in shapes]
+    bc = E.BatchedContraction(einstr, shapes, np.float32, optimize=path, replicas=2)
+    t, c = bc.run_host([ops, [2 * o for o in ops]])
+    assert bc.executor.step_tiles()[0] == (128, 128) and bc.plan.step_infos()[0]["kernel"] == 2
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    for r, f in ((0, 1.0), (1, 2.0 ** len(ops))):
+        got = np.asarray(t[r], dtype=np.float64) * np.exp(float(c[r]))
+        assert np.max(np.abs(got - f * ref)) <= 1e-4 * f * np.max(np.abs(ref))
+    t2, c2 = bc.run_host([ops, [2 * o for o in ops]])
+    assert np.array_equal(t2, t) and np.array_equal(c2, c)           # fixed-order sums: the same bits
+    bc.executor.close()
+
+
+@pytest.mark.parametrize("phys", [2, 4])
+def test_h_form_epilogue_summed_sites(phys, force_h_form):
+    """The batched-MPS site step (`bl,plr->bpr` + `bpr,bp->br` as ONE launch: GEMM with the physical leg re-weighted
+    and summed in the epilogue) on the one-tile-per-CU form, d = 2 and d = 4, ragged batch: against the oracle."""
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from oracle import cpu_ref
+    from tests import networks as nets
+
+    tn, inputs = nets.batched_mps(TN, 5, 64, phys, 600, dtype=np.float32, seed=4)   # (600 x phys x 64 >= 2^16: fused by default)
+    ops = [np.asarray(o) for o in E.make_arg_packer(tn)(tn.params, inputs)]
+    path = ssa_to_linear(nets.batched_mps_path(5), 10)
+    clist = E._contract_path(tn.einsum_str, tuple(o.shape for o in ops), optimize=path, memory_limit=None, use_blas=True)
+    plan = E._native_plan(clist, tuple(o.shape for o in ops), "float32")
+    assert sum(i["epilogue_sum"] == phys for i in plan.step_infos()) == 3
+    ex = engine.Executor(plan)
+    outs, _log, resc = ex.run_host([ops])
+    tiles = ex.step_tiles()
+    assert sum(tl == (128, 128) and i["epilogue_sum"] == phys for tl, i in zip(tiles, plan.step_infos())) == 3, tiles
+    c = E.accumulate_log_scale(resc[0], np.dtype(np.float32))
+    rt, rc = cpu_ref.contract(tn.einsum_str, *ops, path=list(path), split_format=True)
+    got = outs[0].astype(np.float64) * np.exp(float(c))
+    ref = np.asarray(rt, dtype=np.float64) * np.exp(float(rc))
+    assert np.max(np.abs(got - ref)) <= 1e-4 * np.max(np.abs(ref))
+    ex.close()
+
+
+# ---- complex tensors (the reference contracts them through NumPy: modulus norm, real register; SURVEY.md App. A) ------
+@pytest.mark.parametrize("name", ["mps_overlap_5x12x3_c128", "mps_overlap_4x40x4_c64", "mps_overlap_4x10x3_mixed_c128",
+                                  "mps_open_random_c128", "cp_r5_c128"])
+def test_complex_networks_match_the_reference(name):
+    """Fixtures from the unmodified reference on complex NumPy arrays.  The engine computes on (re, im) components
+    (`einsum._complex_plan_cached`: complex x complex steps through the structure tensor of complex multiplication,
+    real x complex steps as they are) and brings the result to the reference's normalisation: mean MODULUS one, the
+    phase kept, a real float64 register - also for torch operands and for the de-stabilised product."""
+    import torch
+
+    g = load_golden(name)
+    ops = g["operands"]
+    c64 = g["t_hat"].dtype == np.complex64
+    tol = 2e-5 if c64 else 1e-11
+    t, c = contract(g["einsum_str"], *ops, optimize=g["path"], split_format=True)
+    assert t.dtype == g["t_hat"].dtype and t.shape == g["t_hat"].shape and c.dtype == np.float64
+    assert abs(np.mean(np.abs(t)) - 1.0) <= 10 * tol
+    assert np.max(np.abs(t - g["t_hat"])) <= tol * max(1.0, float(np.max(np.abs(g["t_hat"]))))
+    assert abs(float(c) - float(g["log_scale"])) <= tol * max(1.0, abs(float(g["log_scale"])))
+    plain = contract(g["einsum_str"], *ops, optimize=g["path"])
+    assert plain.dtype == g["plain"].dtype
+    assert np.max(np.abs(plain - g["plain"])) <= 10 * tol * float(np.max(np.abs(g["plain"])))
+    t_ops = [torch.from_numpy(o) for o in ops]
+    tt, tc = contract(g["einsum_str"], *t_ops, optimize=g["path"], split_format=True)
+    assert tt.dtype == (torch.complex64 if c64 else torch.complex128) and not tc.dtype.is_complex
+    assert np.max(np.abs(tt.numpy() - g["t_hat"])) <= 10 * tol * max(1.0, float(np.max(np.abs(g["t_hat"]))))
