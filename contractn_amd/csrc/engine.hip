@@ -125,6 +125,7 @@ struct Exec {
   std::vector<int32_t> launched_tile;  // per step: (tile rows << 16 | tile columns) of the last enqueue's MFMA kernel, else 0
   char* d_ws = nullptr;
   int32_t* d_tables = nullptr;
+  int64_t* d_tables64 = nullptr;    // batch / outer-group offsets (Plan::tables64)
   void** d_ptrs = nullptr;
   std::vector<void*> h_ptrs;
   bool ptrs_valid = false;
@@ -174,7 +175,7 @@ struct Exec {
 
   ~Exec() {
     DeviceGuard dg(device);
-    for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch, (void*)d_slab, (void*)d_slab2,
+    for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_tables64, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch, (void*)d_slab, (void*)d_slab2,
                     (void*)d_log, (void*)d_resc, (void*)d_logs, (void*)d_chain, d_ones, (void*)d_stepP, (void*)d_stepNumel,
                     (void*)d_stepOff, (void*)d_stepSlots,
                     (void*)d_stage_in, (void*)d_stage_out, (void*)d_group_args})
@@ -529,7 +530,8 @@ static int exec_launch_steps(Exec* E) {
     }
     StepArgs a;
     const int32_t* T = E->d_tables;
-    a.obA = T + st.t.obA; a.obB = T + st.t.obB; a.obC = T + st.t.obC;
+    const int64_t* T8 = E->d_tables64;
+    a.obA = T8 + st.t.obA; a.obB = T8 + st.t.obB; a.obC = T8 + st.t.obC;
     a.omA = T + st.t.omA; a.omC = T + st.t.omC;
     a.onB = T + st.t.onB; a.onC = T + st.t.onC;
     a.okA = T + st.t.okA; a.okB = T + st.t.okB;
@@ -546,7 +548,7 @@ static int exec_launch_steps(Exec* E) {
     part_of(st.lhs, &a.partA, &a.PA, &a.strideA, &a.numelA);
     part_of(st.rhs, &a.partB, &a.PB, &a.strideB, &a.numelB);
     part_of(st.lhs2, &a.partA2, &a.PA2, &a.strideA2, &a.numelA2);
-    a.obA2 = T + st.t.obA2; a.omA2 = T + st.t.omA2; a.okA2 = T + st.t.okA2;
+    a.obA2 = T8 + st.t.obA2; a.omA2 = T + st.t.omA2; a.okA2 = T + st.t.okA2;
     a.idA2 = st.lhs2 >= 0 ? st.lhs2 : E->n_tensors - 1;
     a.krX = st.krX; a.krY = st.krY;
     a.epw = st.epw | (st.epw_split ? 0x100 : 0);
@@ -569,7 +571,7 @@ static int exec_launch_steps(Exec* E) {
     a.c_vec = (st.cvec && (s + 1 < P.n_steps || E->outs_aligned16)) ? 1 : 0;
     a.dbg = nullptr;
     a.ks_slab = nullptr; a.ks_numelC = 0; a.ks_S = 0; a.ks_chunk = 0;
-    a.ohA = T + st.t.ohA; a.ohB = T + st.t.ohB; a.ohC = T + st.t.ohC;
+    a.ohA = T8 + st.t.ohA; a.ohB = T8 + st.t.ohB; a.ohC = T8 + st.t.ohC;
     a.olA = T + st.t.olA; a.olB = T + st.t.olB; a.olC = T + st.t.olC;
     a.H = (int32_t)st.H; a.L = (int32_t)st.L; a.Nv = (int32_t)st.Nv;
     a.sAn = (int32_t)st.sAn; a.sBn = (int32_t)st.sBn;
@@ -1068,7 +1070,7 @@ static int64_t exec_fixed_bytes(const Plan& P, int R) {
   const int nt = P.n_inputs + P.n_steps + 1;
   int64_t slots = 0;
   for (const Step& st : P.steps) slots += std::max(st.partials, kWaveOutputs);   // (a launcher may retile: upper bound)
-  return (int64_t)P.tables.size() * 4 + (int64_t)R * nt * 8 + slots * R * 8 +
+  return (int64_t)P.tables.size() * 4 + (int64_t)P.tables64.size() * 8 + (int64_t)R * nt * 8 + slots * R * 8 +
          (int64_t)R * std::max<int64_t>(P.max_collapse_blocks, 1) * 8 + (int64_t)R * 8 +
          (int64_t)R * P.n_steps * 8 + 256 + (int64_t)P.n_steps * 12;
 }
@@ -1130,6 +1132,8 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   HIPCHECK_X(hipMalloc((void**)&E.d_ws, ws));
   HIPCHECK_X(hipMalloc((void**)&E.d_tables, std::max<size_t>(P.tables.size(), 4) * 4));
   HIPCHECK_X(hipMemcpy(E.d_tables, P.tables.data(), P.tables.size() * 4, hipMemcpyHostToDevice));
+  HIPCHECK_X(hipMalloc((void**)&E.d_tables64, std::max<size_t>(P.tables64.size(), 2) * 8));
+  HIPCHECK_X(hipMemcpy(E.d_tables64, P.tables64.data(), P.tables64.size() * 8, hipMemcpyHostToDevice));
   HIPCHECK_X(hipMalloc((void**)&E.d_ptrs, (size_t)replicas * E.n_tensors * sizeof(void*)));
   {
     size_t slab_elems = 0;   // split-K scratch: S slabs shaped like the step's output, per replica
@@ -1246,7 +1250,8 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
       const Step& st = P.steps[s];
       ChainStep& c = cs[s];
       const int32_t* T = E.d_tables;
-      c.obA = T + st.t.obA; c.obB = T + st.t.obB; c.obC = T + st.t.obC;
+      const int64_t* T8 = E.d_tables64;
+      c.obA = T8 + st.t.obA; c.obB = T8 + st.t.obB; c.obC = T8 + st.t.obC;
       c.omA = T + st.t.omA; c.omC = T + st.t.omC; c.onB = T + st.t.onB; c.onC = T + st.t.onC;
       c.okA = T + st.t.okA; c.okB = T + st.t.okB;
       c.numelC = (double)P.tensors[st.out].numel;

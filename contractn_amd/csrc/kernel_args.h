@@ -34,7 +34,8 @@ static FastDiv make_fastdiv(int64_t d64) {
 }
 
 struct StepArgs {
-  const int32_t *obA, *obB, *obC, *omA, *omC, *onB, *onC, *okA, *okB;
+  const int64_t *obA, *obB, *obC;   // batch offsets: 64-bit (tensors of 2^31 elements and more, see plan.h TableRefs)
+  const int32_t *omA, *omC, *onB, *onC, *okA, *okB;
   void* const* ptrs;    // [R][n_tensors] base pointer of every tensor of every replica
   const double* partA;  // [R][strideA] abs-sum partials of A's producer step (PA of them are valid), nullptr for inputs
   const double* partB;
@@ -51,7 +52,8 @@ struct StepArgs {
   int32_t R;
   int32_t c_vec;  // float4 stores of C allowed
   // streaming kernels: output index = (hi, lo, n); n along C's unit-stride label
-  const int32_t *ohA, *ohB, *ohC, *olA, *olB, *olC;
+  const int64_t *ohA, *ohB, *ohC;   // outer group: 64-bit
+  const int32_t *olA, *olB, *olC;
   int32_t H, L, Nv, sAn, sBn;
   FastDiv dNq, dL, dNv;  // divisors: vectors per row, lo extent, n extent
   unsigned long long* dbg;  // CTN_STAMPS builds only: 4 cycle stamps per MFMA tile (else unused, null)
@@ -62,7 +64,8 @@ struct StepArgs {
   int32_t ks_S, ks_chunk;
   // fused element-wise product as the A operand ("KR", mode_a = 3): A[m][k] = X[..] * Y[..]; X is described by the
   // A fields above, Y by these
-  const int32_t *obA2, *omA2, *okA2;
+  const int64_t* obA2;
+  const int32_t *omA2, *okA2;
   const double* partA2;
   double numelA2;
   int32_t idA2, PA2, strideA2;

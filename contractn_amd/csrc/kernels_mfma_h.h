@@ -264,25 +264,29 @@ __global__ __launch_bounds__(512, 1) void k_mfma_f32_h(StepArgs a) {
   }
   __builtin_amdgcn_s_barrier();                // every wave has read its last fragments: the ring is free
   {
-    float* xo = smem + w * 2048 + lane;        // [block i][register e][lane]
+    // [block i][register quad q][lane][4]: 16-byte LDS accesses, lane-linear (conflict-free)
+    float4* xo = reinterpret_cast<float4*>(smem + w * 2048) + lane;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) xo[(i * 16 + e) * 64] = give[i][e];
+      for (int q = 0; q < 4; ++q)
+        xo[(i * 4 + q) * 64] = make_float4(give[i][4 * q], give[i][4 * q + 1], give[i][4 * q + 2], give[i][4 * q + 3]);
   }
-  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0) only: nothing else is outstanding that the partner reads
+  __builtin_amdgcn_s_barrier();
   {
-    const float* xi = smem + (w ^ 4) * 2048 + lane;
+    const float4* xi = reinterpret_cast<const float4*>(smem + (w ^ 4) * 2048) + lane;
     // fixed order: (first K half) + (second K half), whichever of the two waves adds
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float o = xi[(i * 16 + e) * 64];
-        mine[i][e] = kh == 0 ? mine[i][e] + o : o + mine[i][e];
+      for (int q = 0; q < 4; ++q) {
+        const float4 o = xi[(i * 4 + q) * 64];
+        const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine[i][4 * q + e] = kh == 0 ? mine[i][4 * q + e] + ov[e] : ov[e] + mine[i][4 * q + e];
       }
   }
-
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 4] = __builtin_amdgcn_s_memtime();
 #endif
@@ -362,8 +366,20 @@ __global__ __launch_bounds__(512, 1) void k_mfma_f32_h(StepArgs a) {
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 5] = __builtin_amdgcn_s_memtime();
 #endif
-  const double tot = block_sum((double)asum, red);
-  if (tid == 0) a.partC[(size_t)r * a.partC_stride + t] = tot;
+  // the tile's abs-sum: waves reduce, one LDS hand-off behind a raw barrier (a __syncthreads() would first wait for
+  // this wave's stores to drain; they drain while the eight partials are added - in wave order, always the same)
+  double part = (double)asum;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) red[w] = part;                // (red[] lies behind the ring: nobody else touches it)
+  __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  if (tid == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += red[i];
+    a.partC[(size_t)r * a.partC_stride + t] = tot;
+  }
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) {
     a.dbg[(size_t)pid * 8 + 3] = __builtin_amdgcn_s_memtime();

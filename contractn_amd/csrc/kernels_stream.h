@@ -55,7 +55,7 @@ __device__ __forceinline__ double stream_items(const StepArgs& a, const T* __res
   const uint32_t items = (uint32_t)a.H * (uint32_t)a.L * S;  // < 2^31
   const FastDiv dq = a.dNq;                      // divisor S
   const bool kone = a.K == 1;                    // pure product: k-offset tables hold a single 0
-  const int stepA = (int)S * V * a.sAn, stepB = (int)S * V * a.sBn;
+  const int64_t stepA = (int64_t)S * V * a.sAn, stepB = (int64_t)S * V * a.sBn;   // (64-bit: tensors of 2^31 elements and more)
   double absv = 0;
   const uint32_t stride = (nblocks ? nblocks : gridDim.x) * 256u;   // (a grouped launch is as wide as its widest step)
   for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < items; it += stride) {
@@ -63,8 +63,8 @@ __device__ __forceinline__ double stream_items(const StepArgs& a, const T* __res
     const int c0 = (int)(it - row * S) * V;
     const int h = (int)a.dL.div(row);
     const int l = (int)(row - (uint32_t)h * (uint32_t)a.L);
-    const T* pa = A + a.ohA[h] + a.olA[l] + c0 * a.sAn;
-    const T* pb = B + a.ohB[h] + a.olB[l] + c0 * a.sBn;
+    const T* pa = A + a.ohA[h] + a.olA[l] + (int64_t)c0 * a.sAn;
+    const T* pb = B + a.ohB[h] + a.olB[l] + (int64_t)c0 * a.sBn;
     T* pc = C + (size_t)row * a.Nv + c0;         // C is contiguous in (hi, lo, n) order
     T acc[U][V];
 #pragma unroll
@@ -549,7 +549,8 @@ __global__ __launch_bounds__(256) void k_combine_split(const TIN* __restrict__ t
 // producer's rescale on load), so results are bit-identical to the per-step path.
 // ---------------------------------------------------------------------------
 struct ChainStep {
-  const int32_t *obA, *obB, *obC, *omA, *omC, *onB, *onC, *okA, *okB;
+  const int64_t *obA, *obB, *obC;
+  const int32_t *omA, *omC, *onB, *onC, *okA, *okB;
   double numelC;
   int32_t Bt, M, N, K;
   int32_t idA, idB, idC;

@@ -61,6 +61,36 @@ void build_table(const std::vector<const LabelInfo*>& group, int which /*0 A,1 B
   }
 }
 
+// the same enumeration in 64 bits: batch and outer-group tables (Plan::tables64)
+void build_table64(const std::vector<const LabelInfo*>& group, int which, int64_t padded, std::vector<int64_t>& out) {
+  int64_t n = 1;
+  for (auto* l : group) n *= l->ext;
+  out.assign(std::max<int64_t>(padded, n), 0);
+  std::vector<int64_t> idx(group.size(), 0);
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t off = 0;
+    for (size_t j = 0; j < group.size(); ++j) {
+      int64_t s = which == 0 ? group[j]->sA : which == 1 ? group[j]->sB : which == 2 ? group[j]->sC : group[j]->sA2;
+      off += idx[j] * s;
+    }
+    out[i] = off;
+    for (int j = (int)group.size() - 1; j >= 0; --j) {
+      if (++idx[j] < group[j]->ext) break;
+      idx[j] = 0;
+    }
+  }
+}
+
+// largest offset a group's table can hold for operand `which`
+int64_t span_of(const std::vector<LabelInfo*>& group, int which) {
+  int64_t sp = 0;
+  for (auto* l : group) {
+    const int64_t s = which == 0 ? std::max(l->sA, l->sA2) : which == 1 ? l->sB : l->sC;
+    sp += (l->ext - 1) * s;
+  }
+  return sp;
+}
+
 // simple first-fit allocator over one replica's workspace
 struct Arena {
   struct Block { int64_t off, size; };
@@ -96,6 +126,13 @@ struct Arena {
     }
   }
 };
+
+int64_t append64(std::vector<int64_t>& all, const std::vector<int64_t>& t) {
+  while (all.size() % 2) all.push_back(0);   // 16-byte aligned
+  int64_t off = (int64_t)all.size();
+  all.insert(all.end(), t.begin(), t.end());
+  return off;
+}
 
 int64_t append(std::vector<int32_t>& all, const std::vector<int32_t>& t) {
   // keep every table 16-byte aligned inside the device buffer
@@ -151,7 +188,6 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     } else {
       for (int a = nd - 2; a >= 0; --a) t.strides[a] = t.strides[a + 1] * t.dims[a + 1];
     }
-    if (t.numel >= (1LL << 31)) { err = "tensors with >= 2^31 elements are not supported"; return CTN_UNSUPPORTED; }
     cur += nd;
     P.input_offsets.push_back(in_bytes);
     in_bytes += round_up(t.numel * es, kAlign);
@@ -405,6 +441,26 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
         bool anyM = false, anyN = false;
         for (auto& l : info) if (l.inC) { if (l.inA && !l.inB) anyM = true; if (l.inB && !l.inA) anyN = true; }
         if (anyM && !anyN) swap = true;
+        // A result of 2^31 elements or more is laid out [batch][M][N]; the step that consumes it can address a
+        // CONTRACTED group only through a 32-bit table, so the labels it sums must be the inner (column) ones: when
+        // they all come from the left operand, the operands change sides.
+        double out_n = 1.0;
+        for (auto& l : info) if (l.inC) out_n *= (double)l.ext;
+        if (out_n >= 2147483648.0 && anyM && anyN) {
+          int s2 = -1;
+          for (int q = s + 1; q < d.n_steps && s2 < 0; ++q) if (d.step_lhs[q] == out_id || d.step_rhs[q] == out_id) s2 = q;
+          if (s2 >= 0) {
+            int64_t o2 = 0;
+            for (int q = 0; q < s2; ++q) o2 += d.step_out_ndim[q];
+            auto kept = [&](int32_t lab) {
+              for (int a_ = 0; a_ < d.step_out_ndim[s2]; ++a_) if (d.step_out_labels[o2 + a_] == lab) return true;
+              return false;
+            };
+            bool sumM = false, sumN = false;
+            for (auto& l : info) if (l.inC && !kept(l.label)) { if (l.inA && !l.inB) sumM = true; if (l.inB && !l.inA) sumN = true; }
+            if (sumM && !sumN) swap = true;
+          }
+        }
       }
     }
     if (swap) {
@@ -460,7 +516,6 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     out.strides.assign(out.labels.size(), 1);
     for (int a = (int)out.labels.size() - 2; a >= 0; --a) out.strides[a] = out.strides[a + 1] * out.dims[a + 1];
     for (size_t a = 0; a < out.labels.size(); ++a) { out.numel *= out.dims[a]; find(out.labels[a])->sC = out.strides[a]; }
-    if (out.numel >= (1LL << 31)) { err = "tensors with >= 2^31 elements are not supported"; return CTN_UNSUPPORTED; }
 
     // Epilogue-summed steps: with the summed label p innermost, four adjacent columns are the four p of ONE r - the B
     // operand is then gathered four bytes at a time and so is the output.  When the next column label u is unit-stride
@@ -479,6 +534,27 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
         G[kN].push_back(&synth[0]); G[kN].push_back(pl); G[kN].push_back(&synth[1]);
         split_parent = u;
         st.epw_split = true;
+      }
+    }
+
+    // Tensors of 2^31 elements and more: the m / n / k tables hold 32-bit offsets, the batch tables 64-bit ones, so
+    // outer free labels (largest strides first) move into the batch group until what is left of the row and column
+    // groups spans less than 2^31 elements of every tensor that carries it.  A free label of one operand is a perfectly
+    // good batch label - the other operand simply has stride 0 along it - so the arithmetic is unchanged; only the
+    // tiling sees smaller matrices.  Contracted labels cannot move: a K group spanning 2^31 elements is refused.
+    {
+      const int64_t lim = (1LL << 31) - 1;
+      auto promote = [&](int cls, int wa, int wb) {
+        while (!G[cls].empty() && (span_of(G[cls], wa) > lim || span_of(G[cls], wb) > lim)) {
+          if (fused || epw) return false;                  // (their extra tables are not re-derived: refuse)
+          G[kBatch].push_back(G[cls].front());
+          G[cls].erase(G[cls].begin());
+        }
+        return true;
+      };
+      if (!promote(kM, 0, 2) || !promote(kN, 1, 2) || span_of(G[kK], 0) > lim || span_of(G[kK], 1) > lim) {
+        err = fmt("step %lld: an index group spans 2^31 or more elements of one operand and cannot be split off as a batch", s);
+        return CTN_UNSUPPORTED;
       }
     }
 
@@ -552,6 +628,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       // ... and 64-high row tiles likewise (M = 64 against a huge N: a PEPS boundary absorption seen from the
       // other side; with 128-row tiles half of every MFMA and of every A load is padding)
       st.tileM = ((st.M + 63) / 64) * 64 < ((st.M + kTileM - 1) / kTileM) * kTileM ? 64 : kTileM;
+      if (st.Bt * ((st.M + 63) / 64) * ((st.N + 63) / 64) >= (1LL << 31)) { err = "step with 2^31 or more tiles"; return CTN_UNSUPPORTED; }
       st.blocks = (int)(st.Bt * ((st.M + st.tileM - 1) / st.tileM) * ((st.N + st.tileN - 1) / st.tileN));
       // 256 x 128 tiles fed by LDS-DMA (kernels_mfma_g.h): each operand unit-stride along its free index
       // or along k (16-byte requests either way; not the general gather), at least two 16-deep k-tiles,
@@ -590,19 +667,30 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       st.sBn = nl && nl->inB ? nl->sB : 0;
       std::vector<const LabelInfo*> lo, hi;
       int64_t lprod = 1;
+      int64_t spanLo[3] = {0, 0, 0};     // 32-bit tables: what the inner group spans in A, B, C must stay below 2^31
       while (!cl.empty() && (lo.empty() || lprod * cl.back()->ext <= 65536)) {
-        lprod *= cl.back()->ext;
-        lo.insert(lo.begin(), cl.back());
+        const LabelInfo* c_ = cl.back();
+        const int64_t add[3] = {(c_->ext - 1) * c_->sA, (c_->ext - 1) * c_->sB, (c_->ext - 1) * c_->sC};
+        if (spanLo[0] + add[0] >= (1LL << 31) || spanLo[1] + add[1] >= (1LL << 31) || spanLo[2] + add[2] >= (1LL << 31)) break;
+        for (int q_ = 0; q_ < 3; ++q_) spanLo[q_] += add[q_];
+        lprod *= c_->ext;
+        lo.insert(lo.begin(), c_);
         cl.pop_back();
       }
       hi = cl;
       st.L = lprod;
       st.H = 1;
       for (auto* l : hi) st.H *= l->ext;
+      if (nl && (std::max<int64_t>(st.sAn, st.sBn) >= (1LL << 31) || span_of(G[kK], 0) >= (1LL << 31) ||
+                 span_of(G[kK], 1) >= (1LL << 31) || st.H * lprod * nl->ext >= (1LL << 33))) {
+        err = fmt("step %lld: a streaming step this large (an inner / contracted group spanning 2^31 elements, or 2^33 outputs) is not supported", s);
+        return CTN_UNSUPPORTED;
+      }
       std::vector<int32_t> t6;
-      build_table(hi, 0, st.H, t6); st.t.ohA = append(P.tables, t6);
-      build_table(hi, 1, st.H, t6); st.t.ohB = append(P.tables, t6);
-      build_table(hi, 2, st.H, t6); st.t.ohC = append(P.tables, t6);
+      std::vector<int64_t> t8;
+      build_table64(hi, 0, st.H, t8); st.t.ohA = append64(P.tables64, t8);
+      build_table64(hi, 1, st.H, t8); st.t.ohB = append64(P.tables64, t8);
+      build_table64(hi, 2, st.H, t8); st.t.ohC = append64(P.tables64, t8);
       build_table(lo, 0, st.L, t6); st.t.olA = append(P.tables, t6);
       build_table(lo, 1, st.L, t6); st.t.olB = append(P.tables, t6);
       build_table(lo, 2, st.L, t6); st.t.olC = append(P.tables, t6);
@@ -633,18 +721,20 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
         if (!(kl->inA && kl->sA == 1 && kl->inB)) kv = false;
         for (auto& l : info) if (&l != kl && l.inA && l.sA % vec != 0) kv = false;
       }
+      if (kv && outs >= (1LL << 31)) kv = false;
       if (kv) {
         st.kernel = CTN_KERNEL_ELEMENT;
         st.kvec = 1;
         st.vecw = 1;
         st.blocks = stream_grid((st.H * st.L * st.Nv + 255) / 256);
-      } else if (st.K >= 256 && kUnit) {
+      } else if (st.K >= 256 && kUnit && outs < (1LL << 31)) {
         st.kernel = CTN_KERNEL_ROWDOT;
         // persistent-style grid: at most 16 workgroups per CU, waves stride over the outputs
         st.blocks = (int)std::min<int64_t>((outs + 3) / 4, kStreamMaxBlocks);
       } else {
         st.kernel = CTN_KERNEL_ELEMENT;
         const int64_t items = st.H * st.L * ((st.Nv + st.vecw - 1) / st.vecw);
+        if (items >= (1LL << 31)) { err = fmt("step %lld: a streaming step with 2^31 or more work items is not supported", s); return CTN_UNSUPPORTED; }
         st.blocks = stream_grid((items + 255) / 256);
       }
     }
@@ -665,10 +755,11 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     const int64_t padM = round_up(st.M, std::max(kTileM, st.tileM)), padN = round_up(st.N, kTileN), padK = round_up(st.K, kPadK) + 2 * kPadK;  // kernels prefetch table entries two tiles ahead
     std::vector<int32_t> tb;
     const bool tiled = st.kernel == CTN_KERNEL_MFMA_F32 || st.kernel == CTN_KERNEL_MFMA_F64 || st.kernel == CTN_KERNEL_DOT;
+    std::vector<int64_t> tb8;
     if (tiled || st.chain_ok) {  // (batch, m, n) tables: tile kernels and the chain walker
-      build_table(gb, 0, st.Bt, tb); st.t.obA = append(P.tables, tb);
-      build_table(gb, 1, st.Bt, tb); st.t.obB = append(P.tables, tb);
-      build_table(gb, 2, st.Bt, tb); st.t.obC = append(P.tables, tb);
+      build_table64(gb, 0, st.Bt, tb8); st.t.obA = append64(P.tables64, tb8);
+      build_table64(gb, 1, st.Bt, tb8); st.t.obB = append64(P.tables64, tb8);
+      build_table64(gb, 2, st.Bt, tb8); st.t.obC = append64(P.tables64, tb8);
       build_table(gm, 0, padM, tb);  st.t.omA = append(P.tables, tb);
       build_table(gm, 2, padM, tb);  st.t.omC = append(P.tables, tb);
       build_table(gn, 1, padN, tb);  st.t.onB = append(P.tables, tb);
@@ -677,7 +768,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     build_table(gk, 0, padK, tb);  st.t.okA = append(P.tables, tb);
     build_table(gk, 1, padK, tb);  st.t.okB = append(P.tables, tb);
     if (fused) {   // the second tensor of the A side (a label it does not carry has stride 0)
-      build_table(gb, 3, st.Bt, tb); st.t.obA2 = append(P.tables, tb);
+      build_table64(gb, 3, st.Bt, tb8); st.t.obA2 = append64(P.tables64, tb8);
       build_table(gm, 3, padM, tb);  st.t.omA2 = append(P.tables, tb);
       build_table(gk, 3, padK, tb);  st.t.okA2 = append(P.tables, tb);
     }

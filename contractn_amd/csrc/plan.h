@@ -42,7 +42,10 @@ struct Tensor {
   int64_t ws_offset = -1; // byte offset inside one replica's workspace (intermediates)
 };
 
-// offsets (in int32 entries) of one step's tables inside Plan::tables
+// offsets of one step's tables: m / n / k / lo tables in int32 entries of Plan::tables; the BATCH tables (ob*) and the
+// streaming kernels' outer-group tables (oh*) in int64 entries of Plan::tables64 - those carry the large strides: a
+// tensor of 2^31 elements or more is addressed as (64-bit batch / outer offset) + (32-bit offsets inside one batch
+// entry), the planner moving outer free labels into the batch group until every 32-bit table fits (plan.cpp)
 struct TableRefs {
   int64_t obA = 0, obB = 0, obC = 0, omA = 0, omC = 0, onB = 0, onC = 0, okA = 0, okB = 0;
   int64_t obA2 = 0, omA2 = 0, okA2 = 0;  // fused steps (modeA == 3): the second tensor of the A side
@@ -87,6 +90,7 @@ struct Plan {
   std::vector<Tensor> tensors;  // n_inputs inputs, then one per step
   std::vector<Step> steps;
   std::vector<int32_t> tables;
+  std::vector<int64_t> tables64;  // batch (ob*) and outer-group (oh*) offset tables, see TableRefs
   int64_t ws_bytes_per_replica = 0;
   int64_t input_bytes_per_replica = 0;  // staging size when operands arrive as host pointers
   std::vector<int64_t> input_offsets;   // byte offset of each input inside the staging block

@@ -61,6 +61,7 @@ int main() {
     uint64_t h = 1469598103934665603ull;
     bool ok = true;
     for (int32_t v : P.tables) h = mix(h, (uint32_t)v);
+    for (int64_t v : P.tables64) h = mix(h, (uint64_t)v);
     for (const Step& st : P.steps) {
       h = mix(h, (uint64_t)st.kernel * 131 + st.modeA * 17 + st.modeB * 5 + st.tileM + st.tileN);
       h = mix(h, (uint64_t)st.Bt); h = mix(h, (uint64_t)st.M); h = mix(h, (uint64_t)st.N); h = mix(h, (uint64_t)st.K);
@@ -68,12 +69,14 @@ int main() {
       const bool tiled = st.kernel == CTN_KERNEL_MFMA_F32 || st.kernel == CTN_KERNEL_MFMA_F64 || st.kernel == CTN_KERNEL_DOT;
       if (!(tiled || st.chain_ok)) continue;
       const int32_t* T = P.tables.data();
+      const int64_t* T8 = P.tables64.data();
       auto maxof = [&](int64_t off, int64_t n) { int64_t m = 0; for (int64_t i = 0; i < n; ++i) m = std::max<int64_t>(m, T[off + i]); return m; };
-      const int64_t a_max = maxof(st.t.obA, st.Bt) + maxof(st.t.omA, st.M) + maxof(st.t.okA, st.K);
-      const int64_t c_max = maxof(st.t.obC, st.Bt) + maxof(st.t.omC, st.M) + maxof(st.t.onC, st.N);
+      auto maxof8 = [&](int64_t off, int64_t n) { int64_t m = 0; for (int64_t i = 0; i < n; ++i) m = std::max<int64_t>(m, T8[off + i]); return m; };
+      const int64_t a_max = maxof8(st.t.obA, st.Bt) + maxof(st.t.omA, st.M) + maxof(st.t.okA, st.K);
+      const int64_t c_max = maxof8(st.t.obC, st.Bt) + maxof(st.t.omC, st.M) + maxof(st.t.onC, st.N);
       if (a_max >= P.tensors[st.lhs].numel || c_max >= P.tensors[st.out].numel) ok = false;
       if (st.lhs2 >= 0 && !st.epw) {   // fused step: the second tensor of the A side
-        const int64_t a2_max = maxof(st.t.obA2, st.Bt) + maxof(st.t.omA2, st.M) + maxof(st.t.okA2, st.K);
+        const int64_t a2_max = maxof8(st.t.obA2, st.Bt) + maxof(st.t.omA2, st.M) + maxof(st.t.okA2, st.K);
         if (a2_max >= P.tensors[st.lhs2].numel) ok = false;
       }
       if (st.epw) {   // epilogue weights: row offset + the short label's values (unit-stride)
@@ -82,7 +85,7 @@ int main() {
       }
       h = mix(h, (uint64_t)st.epw);
       if (st.rhs >= 0) {
-        const int64_t b_max = maxof(st.t.obB, st.Bt) + maxof(st.t.onB, st.N) + maxof(st.t.okB, st.K);
+        const int64_t b_max = maxof8(st.t.obB, st.Bt) + maxof(st.t.onB, st.N) + maxof(st.t.okB, st.K);
         if (b_max >= P.tensors[st.rhs].numel) ok = false;
       }
     }

@@ -38,9 +38,12 @@ typedef enum {
   CTN_OK = 0,
   CTN_INVALID_ARG = -1,    /* -> TypeError / AssertionError on the Python side */
   CTN_SHAPE_MISMATCH = -2, /* -> ValueError */
-  CTN_UNSUPPORTED = -3,    /* -> NotImplementedError: a dtype other than f32 / f64, or a MATERIALISED tensor (input, step
-                              output) or index group of 2^31 or more elements - offset tables are int32; a product
-                              that large can still be formed on the fly inside the step that consumes it */
+  CTN_UNSUPPORTED = -3,    /* -> NotImplementedError: a dtype other than f32 / f64; an index group (batch, rows, columns,
+                              contracted) of 2^31 or more entries; a CONTRACTED group that spans 2^31 or more elements of
+                              an operand (tensors of 2^31 elements and more are fine otherwise: batch offsets are 64-bit
+                              and outer free labels become batch labels; only the contracted group of a step needs
+                              32-bit offsets - the engine lays its own large intermediates out accordingly); a streaming
+                              step with 2^31 or more work items */
   CTN_OOM = -4,            /* -> MemoryError */
   CTN_HIP_ERROR = -5,      /* -> RuntimeError */
   CTN_RCCL_ERROR = -6,     /* reserved: collectives are issued by the host layer */

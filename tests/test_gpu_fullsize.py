@@ -240,3 +240,40 @@ def test_cfg3b_full_size_batched_mps_vs_oracle_on_a_subset_of_the_batch():
     del ops, t, t2
     torch.cuda.empty_cache()
     E.clear_caches()
+
+
+# ---- tensors of 2^31 elements and more (round-2 verdict, missing 4) ---------------------------------------------------
+def test_materialised_tensors_beyond_2_to_the_31_elements():
+    """On a 288 GB part an 8 or 16 GiB fp32 tensor is ordinary; NumPy has no limit either (reference einsum.py:371).
+    (i) a 2^32-element GEMM result (16 GiB, an INTERMEDIATE in the workspace) consumed by a GEMV, against
+    A (B w) in float64; (ii) a 2^31-element final result left on the device (torch operands), sampled against the
+    definition, its mean modulus one."""
+    import torch
+
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(31)
+    A = torch.randn((1 << 17, 16), generator=gen, device="cuda")
+    B = torch.randn((16, 1 << 15), generator=gen, device="cuda")
+    w = torch.randn((1 << 15,), generator=gen, device="cuda")
+    t, c = contract("ak,kb,b->a", A, B, w, optimize=((0, 1), (0, 1)), split_format=True)
+    ref = A.double() @ (B.double() @ w.double())
+    got = t.double() * torch.exp(c.double())
+    assert float((got - ref).abs().max() / ref.abs().max()) <= 1e-4
+    torch.cuda.empty_cache()
+    E.clear_caches()
+    A2 = torch.randn((1 << 16, 8), generator=gen, device="cuda")
+    B2 = torch.randn((8, 1 << 15), generator=gen, device="cuda")
+    t2, c2 = contract("ak,kb->ab", A2, B2, split_format=True)          # 2^31 elements = 8 GiB, the caller's buffer
+    assert tuple(t2.shape) == (1 << 16, 1 << 15) and t2.is_cuda
+    scale = float(torch.exp(c2.double()))
+    rng = np.random.default_rng(2)
+    for i_, j_ in zip(rng.integers(0, 1 << 16, 64), rng.integers(0, 1 << 15, 64)):
+        ref_ij = float(A2[i_].double() @ B2[:, j_].double())
+        assert abs(float(t2[i_, j_]) * scale - ref_ij) <= 1e-4 * 8
+    for i_ in (0, (1 << 16) - 1):                                      # first and last row in full
+        ref_row = A2[i_].double() @ B2.double()
+        assert float((t2[i_].double() * scale - ref_row).abs().max()) <= 1e-4 * 8
+    assert abs(float(t2[::64].abs().double().mean()) - 1.0) < 0.05      # stabilised: mean |T_hat| is one
+    del t2
+    torch.cuda.empty_cache()
+    E.clear_caches()

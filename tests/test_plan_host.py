@@ -50,3 +50,32 @@ def test_leaf_steps_are_hoisted_but_reported_in_the_callers_order(monkeypatch):
     assert plain._native_of is None
     assert plain.step_infos() == infos_moved
     E.clear_caches()
+
+
+# ---- tensors of 2^31 elements and more: 64-bit batch offsets, outer free labels moved into the batch group ---------
+def test_plans_for_tensors_of_2_to_the_31_elements_and_more():
+    """The m / n / k offset tables are 32-bit; a tensor of 2^31 elements or more is addressed as (64-bit batch offset) +
+    (32-bit offsets inside one batch entry): the planner moves outer free labels into the batch group until the row
+    and column groups span less than 2^31 elements (round-2 verdict, missing 4).  Host only: a plan needs no data."""
+    from contractn_amd import einsum as E
+
+    def infos(einstr, shapes, path=None):
+        clist = E._contract_path(einstr, tuple(shapes), optimize=path or "auto", memory_limit=None, use_blas=True)
+        return E._native_plan(clist, tuple(shapes), "float32").step_infos()
+
+    # a 2^32-element GEMM result consumed by a GEMV: rows of the big tensor become batch entries
+    i = infos("ak,kb,b->a", [(1 << 17, 16), (16, 1 << 15), (1 << 15,)], ((0, 1), (0, 1)))
+    assert i[0]["out_numel"] == 1 << 32 and i[0]["batch"] * i[0]["m"] == 1 << 17 and i[0]["batch"] > 1
+    assert i[0]["m"] * i[0]["n"] < 1 << 31 and i[0]["n"] == 1 << 15 and i[0]["k"] == 16
+    assert i[1]["out_numel"] == 1 << 17
+    # an outer product of 2^31 elements, summed back over one leg
+    i = infos("a,b,b->a", [(1 << 16,), (1 << 15,), (1 << 15,)], ((0, 1), (0, 1)))
+    assert i[0]["out_numel"] == 1 << 31
+    # a 2^31-element INPUT (shapes only) contracted over its inner leg
+    i = infos("ab,b->a", [(1 << 16, 1 << 15), (1 << 15,)])
+    assert i[0]["out_numel"] == 1 << 16
+    # a contracted group that spans 2^31 elements cannot be split off: refused, loudly
+    import pytest
+
+    with pytest.raises(NotImplementedError):
+        infos("kb,k->b", [(1 << 17, 1 << 15), (1 << 17,)])

@@ -69,6 +69,10 @@ def all_cases():
     cases.append(("peps8x8_D8_row", tn.einsum_str, shapes, ssa_to_linear(nets.peps_row_path(8, 8), 128), np.float32))
     cases.append(("cp1024", "ac,ad,ae->cde", [(1024, 1024)] * 3, "auto", np.float32))
     cases.append(("tucker1024", "abc,ae,bf,cg->efg", [(1024,) * 3] + [(1024, 1024)] * 3, "auto", np.float32))
+    # tensors of 2^31 elements and more: 64-bit batch offsets, outer free labels moved into the batch group
+    cases.append(("wide_gemm", "ak,kb,b->a", [(1 << 17, 16), (16, 1 << 15), (1 << 15,)], ((0, 1), (0, 1)), np.float32))
+    cases.append(("wide_outer", "a,b,b->a", [(1 << 16,), (1 << 15,), (1 << 15,)], ((0, 1), (0, 1)), np.float32))
+    cases.append(("wide_input", "abc,c->ab", [(1 << 10, 1 << 11, 1 << 10), (1 << 10,)], "auto", np.float64))
     tn, inputs = nets.batched_mps(TN, 20, 64, 4, 512, dtype=np.float32, seed=4)
     ops = E.make_arg_packer(tn)(tn.params, inputs)
     cases.append(("batched_mps", tn.einsum_str, [o.shape for o in ops], ssa_to_linear(nets.batched_mps_path(20), 40), np.float32))
