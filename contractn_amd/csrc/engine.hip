@@ -1061,6 +1061,12 @@ int ctn_plan_out_dims(const ctn_plan* plan, int64_t* dims) {
   for (size_t i = 0; i < d.size(); ++i) dims[i] = d[i];
   return CTN_OK;
 }
+int ctn_plan_out_labels(const ctn_plan* plan, int32_t* labels) {
+  if (!plan || !labels) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+  const auto& l = plan->p.output().labels;
+  for (size_t i = 0; i < l.size(); ++i) labels[i] = l[i];
+  return CTN_OK;
+}
 int64_t ctn_plan_out_numel(const ctn_plan* plan) { return plan ? plan->p.output().numel : 0; }
 int64_t ctn_plan_out_bytes(const ctn_plan* plan) {
   return plan ? plan->p.output().numel * (int64_t)plan->p.elem_size() : 0;

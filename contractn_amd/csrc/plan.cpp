@@ -151,7 +151,8 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
   P.dtype = d.dtype;
   P.n_inputs = d.n_inputs;
   P.n_steps = d.n_steps;
-  P.stabilize = d.stabilize != 0;
+  P.stabilize = (d.stabilize & 1) != 0;
+  P.free_out_order = (d.stabilize & 2) != 0;
   P.min_norm = d.min_norm;
   const int64_t es = (int64_t)P.elem_size();
   const int64_t vec = 16 / es;  // elements per 16-byte vector load
@@ -352,7 +353,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     Step st;
     const int out_id = d.n_inputs + s;
     int lhs = d.step_lhs[s], rhs = d.step_rhs[s];
-    const bool last = s == d.n_steps - 1;
+    const bool last = s == d.n_steps - 1 && !P.free_out_order;   // (free order: the last result is laid out like any other)
     if (lhs < 0 || lhs >= out_id || rhs < -1 || rhs >= out_id || lhs == rhs) {
       err = fmt("step %lld references invalid operands (%lld, %lld)", s, lhs, rhs);
       return CTN_INVALID_ARG;
@@ -777,7 +778,7 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     }
 
     // -- workspace: allocate the output, then release the consumed intermediates
-    if (!last) out.ws_offset = arena.alloc(out.numel * es);
+    if (s != d.n_steps - 1) out.ws_offset = arena.alloc(out.numel * es);   // (the final result is the caller's buffer)
     for (int id : {lhs, rhs, st.lhs2}) {
       if (id >= d.n_inputs) arena.release(P.tensors[id].ws_offset, P.tensors[id].numel * es);
     }

@@ -86,6 +86,7 @@ struct Plan {
   int n_inputs = 0;
   int n_steps = 0;
   bool stabilize = true;
+  bool free_out_order = false;   // the last step's result takes the engine's natural layout (ctn_plan_desc.stabilize bit 1)
   double min_norm = 1e-7;
   std::vector<Tensor> tensors;  // n_inputs inputs, then one per step
   std::vector<Step> steps;

@@ -799,6 +799,7 @@ class SlicedContraction:
             torch.cuda.current_stream(dev).synchronize()
         self.last_slices = None   # (T_hat [n_local, ...], log_scale [n_local]) of the last local_result()
         self._join = None         # device / pinned buffers of run_small, allocated on first use
+        self.root_members = [[i] for i in range(len(self.my_slices))]   # (uniform with StagedSlicedContraction)
 
     def slices_host(self):
         """``(T_hat [n_local, ...], c [n_local])`` of this rank's slices, through the checked host path."""
@@ -1081,10 +1082,20 @@ def stage_decomposition(einstr, shapes, slice_labels, path, min_saved=1 << 28):
         return {lab for lab, c in count[v].items() if lab in out_set or c < total[lab]}
 
     def result_term(v):
+        """Axis order of a stage's result.  The engine lays a step's output out as [rows from the left operand][columns
+        from the right one] and honours the caller's order for the LAST step of a plan only - which a stage's result
+        is: the labels that come from the second child of the stage's last step go innermost (columns: 16-byte stores,
+        the large-tile kernels stay eligible), each side sorted by extent."""
         if v == root:
             return out
         keep = labels_of(v) - set(sl)
-        return "".join(lab for _d, lab in sorted((sizes[lab], lab) for lab in keep))
+        a, b = kids[v]
+        from_b = keep & labels_of(b)
+        if not from_b or from_b == keep:
+            return "".join(lab for _d, lab in sorted((sizes[lab], lab) for lab in keep))
+        side_a = [lab for _d, lab in sorted((sizes[lab], lab) for lab in keep - from_b)]
+        side_b = [lab for _d, lab in sorted((sizes[lab], lab) for lab in from_b)]
+        return "".join(side_a + side_b)
 
     sz1 = dict(sizes)
     for lab in sl:
@@ -1361,6 +1372,14 @@ class StagedSlicedContraction:
     when the evaluations that group needs differ from the ones it holds (`paths.hoisted_profile(outer=...)` counts
     exactly that).  ``None`` = the smallest count whose buffers fit ``held_budget`` bytes.
 
+    ``unslice``: at the ROOT stage a sliced label may become an ordinary contracted label again - its values then lie
+    side by side in the stage buffers below (one more, strided axis of those operands) and the root sums over it
+    inside its own GEMMs instead of once per value.  Worth it when another large operand of the root does not depend
+    on the label: 8 x 8 PEPS, D = 16, the root's 2^28-element operand was read 16 times, once per value of the third
+    label, by GEMMs with 16 rows; un-sliced, it is read once by one GEMM with 256 rows.  The slices of such an operand
+    come with different scales: they are brought to their common maximum first (one pass over the buffer, on the
+    device).  Only labels that are not walked on the host, while the root's intermediates stay below ``unslice_limit``.
+
     Ranks: the grid of label values is cut into one BLOCK per rank (`_best_rank_grid`: the factorisation of the
     ranks over the labels under which the busiest rank has least to do); of a lower stage a rank evaluates what its
     block projects onto (a stage that depends on no sliced label is computed by every rank - that work does not
@@ -1368,7 +1387,8 @@ class StagedSlicedContraction:
     ``optimize`` must be an explicit linear path (the one the labels were chosen with)."""
 
     def __init__(self, einstr, operands, slice_labels, optimize, rank=0, world=1, device=0, dtype=None,
-                 workspace_budget=64 << 30, min_saved=1 << 28, outer=None, held_budget=64 << 30):
+                 workspace_budget=64 << 30, min_saved=1 << 28, outer=None, held_budget=64 << 30, unslice=True,
+                 unslice_limit=1 << 28, unslice_min_numel=1 << 22):
         import torch
 
         from . import einsum as E
@@ -1437,6 +1457,39 @@ class StagedSlicedContraction:
         self.outer = int(outer)
         groups, need = grouping(self.outer)
         self.n_groups = len(groups)
+        # labels the root takes back as ordinary contracted labels (see the class docstring)
+        root_desc = self.stage_desc[-1]
+        self.unsliced = ()
+        if unslice and n_stage > 1:
+            chosen = []
+            for lab in reversed(self.slice_labels[self.outer:]):          # innermost (fastest-varying) label first
+                carriers, others = [], []
+                for kind, j in root_desc["operands"]:
+                    has = (lab in terms[j]) if kind == "in" else (lab in self.stage_desc[j]["dep"])
+                    (carriers if has else others).append((kind, j))
+                if not carriers or any(kind == "in" for kind, _j in carriers):
+                    continue
+                if not any(kind == "st" and stage_numel[j] >= unslice_min_numel for kind, j in others):
+                    continue                                              # nothing large is re-read: not worth a pass
+                trial = chosen + [lab]
+                r_terms = []
+                for kind, j in root_desc["operands"]:
+                    if kind == "in":
+                        r_terms.append("".join(c for c in terms[j] if c not in self.slice_labels))
+                    else:
+                        r_terms.append("".join(c for c in self.stage_desc[j]["dep"] if c in trial) + self.stage_desc[j]["out"])
+                big = paths.path_cost([set(t_) for t_ in r_terms], out, sizes, root_desc["path"])[1] if len(r_terms) > 1 else 0
+                if big <= unslice_limit:
+                    chosen = trial
+            self.unsliced = tuple(lab for lab in self.slice_labels if lab in chosen)
+        root_dep = [lab for lab in root_desc["dep"] if lab not in self.unsliced]
+        dep_idx[-1] = [at[lab] for lab in root_dep]
+        need[-1] = [sorted({tuple(v[i] for i in dep_idx[-1]) for v in grp}) for grp in groups]
+        self.root_members = []      # per root evaluation (in buffer order): indices into my_slices of the slices it sums
+        where = {v: q for q, v in enumerate(self.my_slices)}
+        for grp, wanted in zip(groups, need[-1]):
+            for e in wanted:
+                self.root_members.append([where[v] for v in grp if tuple(v[i] for i in dep_idx[-1]) == e])
 
         self.tstream = torch.cuda.Stream(dev)
         # inputs: sliced axes first (in slice_labels order), so a slice is one contiguous block at a pointer offset
@@ -1467,17 +1520,57 @@ class StagedSlicedContraction:
         n_local = len(self.my_slices)
         for k, st in enumerate(self.stage_desc):
             root = k == n_stage - 1
-            n_buf = n_local if root else max(len(x) for x in need[k])
-            lhs = st["einsum"].split("->")[0].split(",")
-            st_shapes = [tuple(sizes[c] for c in t_) for t_ in lhs]
-            probe = E._native_plan(E._contract_path(st["einsum"], tuple(st_shapes), optimize=_hashable(st["path"]),
-                                                    memory_limit=None, use_blas=True), tuple(st_shapes), self.np_dtype.name)
+            n_buf = len(self.root_members) if root else max(len(x) for x in need[k])
+            # the stage's einsum over its operands: a lower stage's result in the axis order its plan chose (below the
+            # root the engine lays results out itself - rows of the last step's left operand, then columns of its right
+            # one - so that the step keeps its 16-byte stores and large tiles; only the root has the caller's order)
+            lhs, st_shapes, st_strides = [], [], []
+            for kind, j in st["operands"]:
+                if kind == "in":
+                    t_ = "".join(c for c in terms[j] if c not in self.slice_labels)
+                    lhs.append(t_)
+                    st_shapes.append(tuple(sizes[c] for c in t_))
+                    st_strides.append(None)
+                    continue
+                child = self.stages[j]
+                inner = tuple(sizes[c] for c in child["out_term"])
+                inner_strides = [1] * len(inner)
+                for a_ in range(len(inner) - 2, -1, -1):
+                    inner_strides[a_] = inner_strides[a_ + 1] * inner[a_ + 1]
+                extra = [lab for lab in child["desc"]["dep"] if root and lab in self.unsliced]
+                # an un-sliced label is one more axis of the child's buffer: its values lie `stride x (evaluations per
+                # step of the label)` elements apart (the evaluations of a group are a grid over the child's labels)
+                ex_shape, ex_stride = [], []
+                for lab in extra:
+                    pos_ = child["desc"]["dep"].index(lab)
+                    counts = [len({e[q] for e in need[j][0]}) for q in range(len(child["desc"]["dep"]))]
+                    ex_shape.append(counts[pos_])
+                    ex_stride.append(int(np.prod(counts[pos_ + 1:])) * child["stride"])
+                lhs.append("".join(extra) + child["out_term"])
+                st_shapes.append(tuple(ex_shape) + inner)
+                st_strides.append(tuple(ex_stride) + tuple(inner_strides) if extra else None)
+            st_einsum = ",".join(lhs) + "->" + st["out"]
+            have_strides = any(x is not None for x in st_strides)
+            if have_strides:
+                def contiguous(shape):
+                    out_, acc = [], 1
+                    for d_ in reversed(shape):
+                        out_.append(acc)
+                        acc *= d_
+                    return tuple(reversed(out_))
+                st_strides = tuple(x if x is not None else contiguous(shp) for x, shp in zip(st_strides, st_shapes))
+            else:
+                st_strides = None
+            probe = E._native_plan(E._contract_path(st_einsum, tuple(st_shapes), optimize=_hashable(st["path"]),
+                                                    memory_limit=None, use_blas=True), tuple(st_shapes), self.np_dtype.name,
+                                   not root, st_strides)
             per = max(1, probe.workspace_bytes(2) - probe.workspace_bytes(1))
             R = int(max(1, min(max(len(x) for x in need[k]), workspace_budget // per)))
-            bc = E.BatchedContraction(st["einsum"], st_shapes, self.np_dtype, optimize=st["path"], replicas=R, device=device,
-                                      stream=self.tstream.cuda_stream)
+            bc = E.BatchedContraction(st_einsum, st_shapes, self.np_dtype, optimize=st["path"], replicas=R, device=device,
+                                      stream=self.tstream.cuda_stream, free_output_order=not root, in_strides=st_strides)
             self.stages.append({
                 "desc": st, "bc": bc, "R": R, "numel": stage_numel[k], "stride": stage_stride[k],
+                "out_term": st["out"] if root else bc.out_subscripts,
                 "out": torch.zeros((n_buf, stage_stride[k]), device=dev, dtype=tdt),
                 "scratch": torch.zeros((R, stage_stride[k]), device=dev, dtype=tdt),
                 "c": torch.zeros(n_buf, dtype=torch.float64, device=dev),
@@ -1498,9 +1591,23 @@ class StagedSlicedContraction:
                 holds[k] = want
                 slot0 = done if root else 0
                 pos_child = {j: {e: q for q, e in enumerate(holds[j])} for kind, j in st["operands"] if kind == "st"}
-                proj = {j: [st["dep"].index(lab) for lab in self.stage_desc[j]["dep"]] for j in pos_child}
+                # the child's evaluation for one of ours: our label values, and for a label the root has un-sliced the
+                # FIRST value of the group (the others lie behind it along the extra axis)
+                first = {lab: min(v[at[lab]] for v in slices) for lab in self.unsliced} if root else {}
 
-                def eval_ptrs(e, st=st, k=k, pos_child=pos_child, proj=proj):
+                def child_eval(e, j, k=k, first=first):
+                    mine = dict(zip(dep_idx[k], e))
+                    return tuple(mine[at[lab]] if at[lab] in mine else first[lab] for lab in self.stage_desc[j]["dep"])
+
+                if root and self.unsliced:
+                    for j in pos_child:                      # bring the slices along the un-sliced axes to a common scale
+                        dep_j = self.stage_desc[j]["dep"]
+                        axes = [q for q, lab in enumerate(dep_j) if lab in self.unsliced]
+                        if axes:
+                            grid = [len({e[q] for e in holds[j]}) for q in range(len(dep_j))]
+                            self.schedule.append(("merge", j, len(holds[j]), tuple(grid), tuple(axes)))
+
+                def eval_ptrs(e, st=st, k=k, pos_child=pos_child, child_eval=child_eval):
                     full = [0] * len(self.slice_labels)
                     for i, v in zip(dep_idx[k], e):
                         full[i] = v
@@ -1509,7 +1616,7 @@ class StagedSlicedContraction:
                         if kind == "in":
                             ptrs.append(input_ptr(j, full))
                         else:
-                            q = pos_child[j][tuple(e[i] for i in proj[j])]
+                            q = pos_child[j][child_eval(e, j)]
                             ptrs.append(self.stages[j]["out"].data_ptr() + q * self.stages[j]["stride"] * item)
                     return ptrs
 
@@ -1526,13 +1633,13 @@ class StagedSlicedContraction:
                     S["launches"] += 1
                     S["evaluated"] += n
                 # scales of the stages below ride along with their results: cum = own + sum of the children's
-                kids_idx = [(j, torch.as_tensor([pos_child[j][tuple(e[i] for i in proj[j])] for e in want], dtype=torch.int64, device=dev))
+                kids_idx = [(j, torch.as_tensor([pos_child[j][child_eval(e, j)] for e in want], dtype=torch.int64, device=dev))
                             for j in pos_child]
                 self.schedule.append(("cum", k, slot0, len(want), kids_idx))
-            done += len(slices)
+            done += len(need[-1][g])
         root = self.stages[-1]
         numel = max(1, int(np.prod(self.out_shape)))
-        assert root["numel"] == numel and done == n_local
+        assert root["numel"] == numel and done == len(self.root_members)
         self.R = root["R"]
         self._join = {"numel": numel, "packed": torch.zeros(numel + 1, dtype=torch.float64, device=dev),
                       "gathered": torch.zeros(world * (numel + 1), dtype=torch.float64, device=dev),
@@ -1545,11 +1652,12 @@ class StagedSlicedContraction:
         return [(S["bc"], S["evaluated"], S["R"], S["launches"]) for S in self.stages]
 
     def slices_host(self):
-        """``(T_hat [n_local, ...], c [n_local])`` of this rank's slices as the LAST run left them on the device (the
-        root stage's results with the scales of the stages below added) - for slice-by-slice checks."""
+        """``(T_hat [n, ...], c [n])`` of the root stage's evaluations as the LAST run left them on the device (with the
+        scales of the stages below added) - for slice-by-slice checks: evaluation q is the sum of this rank's slices
+        ``root_members[q]`` (one slice each unless the root took sliced labels back, ``unsliced``)."""
         root = self.stages[-1]
         self.tstream.synchronize()
-        t = root["out"][:, :root["numel"]].cpu().numpy().reshape((len(self.my_slices),) + self.out_shape)
+        t = root["out"][:, :root["numel"]].cpu().numpy().reshape((len(self.root_members),) + self.out_shape)
         return t, root["cum"].cpu().numpy()
 
     def evaluations(self):
@@ -1572,6 +1680,18 @@ class StagedSlicedContraction:
                     S = self.stages[k]
                     launch()
                     S["bc"].executor.snapshot_scales(S["c"].data_ptr() + 8 * slot, n, resc.data_ptr())
+                elif entry[0] == "merge":
+                    # the evaluations of stage j along the un-sliced axes become ONE operand of the root: bring them to
+                    # their common (largest) scale - exact zeros aside - and let that scale ride along
+                    _tag, j, n, grid, axes = entry
+                    S = self.stages[j]
+                    buf = S["out"][:n]
+                    cum = S["cum"][:n].reshape(grid)
+                    live = buf[:, :min(64, S["numel"])].ne(0).any(dim=1).reshape(grid)
+                    top = torch.where(live, cum, torch.full_like(cum, float("-inf"))).amax(dim=axes, keepdim=True)
+                    top = torch.where(torch.isinf(top), torch.zeros_like(top), top)
+                    buf.mul_(torch.exp(cum - top).reshape(n, 1).to(buf.dtype))
+                    S["cum"][:n] = top.expand(grid).reshape(n)
                 else:
                     _tag, k, slot0, n, kids_idx = entry
                     S = self.stages[k]
@@ -1579,7 +1699,7 @@ class StagedSlicedContraction:
                     for j, idx in kids_idx:
                         cum = cum + self.stages[j]["cum"].index_select(0, idx)
                     S["cum"][slot0:slot0 + n] = cum
-            ex.combine_split(root["out"].data_ptr(), root["stride"], root["cum"].data_ptr(), 1, len(self.my_slices),
+            ex.combine_split(root["out"].data_ptr(), root["stride"], root["cum"].data_ptr(), 1, len(self.root_members),
                              J["numel"], J["packed"].data_ptr())
         self.tstream.synchronize()
         suspect = any(self.stages[e[1]]["bc"].executor.scales_suspect(e[5].data_ptr(), e[4]) for e in self.schedule if e[0] == "launch")

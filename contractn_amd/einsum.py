@@ -168,22 +168,24 @@ def lower_contraction_list(n_operands, contract_list, shapes=None):
 
 
 @lru_cache(maxsize=256)
-def _native_plan_cached(contract_list, shapes, dtype_name):
+def _native_plan_cached(contract_list, shapes, dtype_name, free_output_order=False, in_strides=None):
     in_labels, steps = lower_contraction_list(len(shapes), contract_list, shapes)
     for lab, shp in zip(in_labels, shapes):
         if len(lab) != len(shp):
             raise ValueError(f"operand of shape {shp} does not match its {len(lab)} subscripts")
-    return engine.Plan(dtype_name, in_labels, shapes, steps, stabilize=True, min_norm=MIN_NORM)
+    return engine.Plan(dtype_name, in_labels, shapes, steps, stabilize=True, min_norm=MIN_NORM,
+                       free_output_order=free_output_order, in_strides=in_strides)
 
 
 _PLAN_LOCK = threading.Lock()
 
 
-def _native_plan(contract_list, shapes, dtype_name):
+def _native_plan(contract_list, shapes, dtype_name, free_output_order=False, in_strides=None):
     """Cached native plan.  (``lru_cache`` does not serialise misses: without the lock two threads asking for
-    the same new plan would each build one, and executors are keyed by plan identity.)"""
+    the same new plan would each build one, and executors are keyed by plan identity.)  ``in_strides``: element
+    strides per operand axis (tuples), None = C-contiguous operands."""
     with _PLAN_LOCK:
-        return _native_plan_cached(contract_list, shapes, dtype_name)
+        return _native_plan_cached(contract_list, shapes, dtype_name, free_output_order, in_strides)
 
 
 _native_plan.cache_clear = _native_plan_cached.cache_clear
@@ -582,7 +584,7 @@ class BatchedContraction:
     """
 
     def __init__(self, einstr, shapes, dtype, optimize="auto", replicas=1, device=0, stream=None,
-                 memory_limit=None, use_blas=True):
+                 memory_limit=None, use_blas=True, free_output_order=False, in_strides=None):
         if not isinstance(optimize, (str, bool)) and optimize is not None:
             optimize = tuple(tuple(int(p) for p in step) for step in optimize)
         shapes = tuple(tuple(int(d) for d in s) for s in shapes)
@@ -590,7 +592,11 @@ class BatchedContraction:
         self.dtype = np.dtype(dtype)
         self.contract_list = _contract_path(einstr, shapes, optimize=optimize,
                                             memory_limit=memory_limit, use_blas=use_blas)
-        self.plan = _native_plan(self.contract_list, shapes, self.dtype.name)
+        # free_output_order: the result's axis order is the engine's choice (``out_subscripts`` tells which)
+        if in_strides is not None:
+            in_strides = tuple(tuple(int(x) for x in st_) for st_ in in_strides)
+        self.plan = _native_plan(self.contract_list, shapes, self.dtype.name, free_output_order, in_strides)
+        self.out_subscripts = "".join(chr(l_) for l_ in self.plan.out_labels)
         self.replicas = int(replicas)
         self.executor = engine.Executor(self.plan, replicas=self.replicas, device=device, stream=stream)
 

@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "ctn_version", "ctn_last_error", "ctn_device_count",
     "ctn_plan_create", "ctn_plan_destroy", "ctn_plan_dtype", "ctn_plan_n_inputs",
     "ctn_plan_n_steps", "ctn_plan_flops", "ctn_plan_bytes_min", "ctn_plan_out_ndim",
-    "ctn_plan_out_dims", "ctn_plan_out_numel", "ctn_plan_out_bytes",
+    "ctn_plan_out_dims", "ctn_plan_out_labels", "ctn_plan_out_numel", "ctn_plan_out_bytes",
     "ctn_plan_workspace_bytes", "ctn_plan_step_info",
     "ctn_exec_create", "ctn_exec_destroy", "ctn_exec_run", "ctn_exec_enqueue",
     "ctn_exec_fetch", "ctn_exec_synchronize", "ctn_exec_set_timing", "ctn_exec_step_ms",
@@ -138,6 +138,7 @@ def load_library():
         "ctn_plan_bytes_min": (i64, [vp]),
         "ctn_plan_out_ndim": (i32, [vp]),
         "ctn_plan_out_dims": (i32, [vp, C.POINTER(C.c_int64)]),
+        "ctn_plan_out_labels": (i32, [vp, C.POINTER(C.c_int32)]),
         "ctn_plan_out_numel": (i64, [vp]),
         "ctn_plan_out_bytes": (i64, [vp]),
         "ctn_plan_workspace_bytes": (i64, [vp, i32]),
@@ -234,8 +235,10 @@ class Plan:
     """Immutable native plan for one (einsum string, shapes, path, dtype)."""
 
     def __init__(self, dtype, in_labels, in_dims, steps, stabilize=True, min_norm=1e-7,
-                 in_strides=None):
-        """``in_labels``/``in_dims``: per-operand int lists; ``steps``: (lhs, rhs|-1, out_labels)."""
+                 in_strides=None, free_output_order=False):
+        """``in_labels``/``in_dims``: per-operand int lists; ``steps``: (lhs, rhs|-1, out_labels).
+        ``free_output_order``: the engine also picks the axis order of the final result (``out_labels`` tells which):
+        for results that only feed another plan (the stages of a sliced contraction)."""
         lib = load_library()
         self.np_dtype = np.dtype(dtype)
         if self.np_dtype == np.float32:
@@ -270,7 +273,7 @@ class Plan:
         desc.step_rhs = _ptr(rhs, C.c_int32)
         desc.step_out_ndim = _ptr(ond, C.c_int32)
         desc.step_out_labels = _ptr(olab, C.c_int32)
-        desc.stabilize = 1 if stabilize else 0
+        desc.stabilize = (1 if stabilize else 0) | (2 if free_output_order else 0)
         desc.min_norm = float(min_norm)
         handle = C.c_void_p()
         _check(lib.ctn_plan_create(C.byref(desc), C.byref(handle)))
@@ -282,6 +285,9 @@ class Plan:
         od = (C.c_int64 * max(nd, 1))()
         _check(lib.ctn_plan_out_dims(handle, od))
         self.out_shape = tuple(int(od[i]) for i in range(nd))
+        ol = (C.c_int32 * max(nd, 1))()
+        _check(lib.ctn_plan_out_labels(handle, ol))
+        self.out_labels = tuple(int(ol[i]) for i in range(nd))
         self.flops = float(lib.ctn_plan_flops(handle))
         self.bytes_min = int(lib.ctn_plan_bytes_min(handle))
         self.out_bytes = int(lib.ctn_plan_out_bytes(handle))

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CTN_ABI_VERSION 3
+#define CTN_ABI_VERSION 4
 
 typedef enum {
   CTN_OK = 0,
@@ -96,7 +96,11 @@ typedef struct {
   const int32_t* step_out_ndim;   /* [n_steps] */
   const int32_t* step_out_labels; /* [sum step_out_ndim]; axis order is honoured for the LAST
                                      step only - intermediates are laid out by the engine */
-  int32_t stabilize;              /* 1 = rescale after every step (reference einsum.py:387) */
+  int32_t stabilize;              /* 1 = rescale after every step (reference einsum.py:387); bit 1 (value 2) set in
+                                     addition: the engine also chooses the axis order of the LAST step's result (its
+                                     natural [batch][rows][columns] layout, read back with ctn_plan_out_labels) - for
+                                     results that only feed another plan of the same caller (stages of a sliced
+                                     contraction): the reference's results always have the caller's order */
   double min_norm;                /* 1e-7 in the reference (einsum.py:94) */
 } ctn_plan_desc;
 
@@ -139,6 +143,8 @@ double ctn_plan_flops(const ctn_plan* plan);
 int64_t ctn_plan_bytes_min(const ctn_plan* plan);
 int ctn_plan_out_ndim(const ctn_plan* plan);
 int ctn_plan_out_dims(const ctn_plan* plan, int64_t* dims /* [out_ndim] */);
+/* labels of the result's axes, in order (the caller's own unless the plan was created with the free-order bit) */
+int ctn_plan_out_labels(const ctn_plan* plan, int32_t* labels /* [out_ndim] */);
 int64_t ctn_plan_out_numel(const ctn_plan* plan);
 int64_t ctn_plan_out_bytes(const ctn_plan* plan);
 /* device bytes an executor for `replicas` simultaneous contractions will allocate */

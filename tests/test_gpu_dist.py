@@ -447,6 +447,19 @@ def test_staged_slicing_equals_plain_slicing_and_the_unsliced_value():
         assert max(S["out"].shape[0] for S in looped.stages[:-1]) <= max(S["out"].shape[0] for S in st.stages[:-1])
     tight = dist.StagedSlicedContraction(tn.einsum_str, ops, labels, optimize=path, min_saved=1 << 12, held_budget=1)
     assert tight.outer == len(labels)                  # nothing fits: every label walked on the host
+    # the root takes sliced labels back as ordinary contracted labels (forced here; by default only when a large operand
+    # of the root would otherwise be re-read): fewer root evaluations, each the sum of several slices, the same value
+    back = dist.StagedSlicedContraction(tn.einsum_str, ops, labels, optimize=path, min_saved=1 << 12, unslice_min_numel=1)
+    if back.unsliced:
+        assert len(back.root_members) < rep["slices"] and sum(len(m) for m in back.root_members) == rep["slices"]
+        for _ in range(3):
+            t_b, c_b = back.run()
+            assert float(t_b) == float(t_s) and abs(float(c_b) - float(c_s)) <= 1e-5
+        bt, bc_ = back.slices_host()
+        for q, grp in enumerate(back.root_members):     # every root evaluation = the split-format sum of its slices
+            rt, rc = dist.combine_split([(pt[i], pc[i]) for i in grp])
+            assert float(bt[q]) == float(rt) and abs(float(bc_[q]) - float(rc)) <= 2e-5
+    assert st.unsliced == ()                            # tiny operands: not worth a pass by default
     # two emulated ranks: disjoint halves of the slices, lower stages only where their slices need them
     parts = []
     for rank in range(2):
