@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--plain-slicing", action="store_true",
                     help="peps: every slice repeats the whole path (dist.SlicedContraction) instead of the staged form, in "
                          "which slice-independent parts of the tree are contracted once (dist.StagedSlicedContraction)")
+    ap.add_argument("--cross-check", action="store_true",
+                    help="peps: contract the network once more on a different slicing (other labels, another tree) and "
+                         "report the distance between the two values")
     ap.add_argument("--single-gpu-reference", action="store_true",
                     help="peps: rank 0 also measures the best single-GPU form of the same network (unsliced where it fits, "
                          "and the sliced plan on one GPU) and the line reports the speed-up against it")
@@ -301,13 +304,14 @@ def peps_secondary(args, result, world, rank, local_rank, backend, dev):
             a2.rows, a2.cols, a2.bond, a2.slices, a2.max_intermediate = 8, 8, bond, slices, max_int
             a2.steps, a2.warmup, a2.no_cpu_baseline, a2.dump_steps, a2.event_passes = steps, warmup, True, None, 1
             a2.single_gpu_reference = True
+            a2.cross_check = bond == 16        # D = 16 has no CPU oracle: two different slicings must agree
             try:
                 full = run_peps(a2, world, rank, local_rank, backend, dev)
             except Exception as exc:  # noqa: BLE001 - recorded, the headline line must still be printed
                 full = {"error": repr(exc)}
             if rank == 0:
                 keep = ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "achieved_tflops", "result", "error",
-                        "strong_scaling")
+                        "strong_scaling", "cross_check")
                 short = {k: full[k] for k in keep if k in full}
                 if "config" in full:
                     short["config"] = {k: full["config"][k] for k in ("workload", "slices", "slices_per_gpu",
@@ -632,25 +636,50 @@ def run_peps(args, world, rank, local_rank, backend, dev):
         elapsed = float(tmax.item())
         dist.all_reduce(evals_all, op=dist.ReduceOp.SUM)
     evals_all = evals_all.cpu().numpy()
+    # everything the accounting below needs, as plain data: the executors can then be freed (the cross-check and the
+    # single-GPU references build their own)
+    class StageData:
+        pass
+
+    stage_data = []
+    for k_, (bc_, n_loc, R_, chunks_) in enumerate(stages):
+        sd = StageData()
+        sd.infos, sd.tiles = bc_.plan.step_infos(), bc_.executor.step_tiles()
+        sd.step_strs = [c[2] for c in bc_.contract_list]
+        sd.flops, sd.n_steps, sd.R, sd.launches, sd.evaluated = bc_.plan.flops, bc_.plan.n_steps, R_, chunks_, n_loc
+        sd.dep = len(sc.stage_desc[k_]["dep"]) if staged else len(labels)
+        stage_data.append(sd)
+    sizes, n_total, n_mine, sc_R, sc_outer = sc.sizes, sc.n_total, len(sc.my_slices), sc.R, getattr(sc, "outer", 0)
+    sc_unsliced = len(getattr(sc, "unsliced", ()))
+    cpu_check = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_check = peps_cpu_baseline(sc, einstr, ops, labels, path, args.cpu_seconds)
+    del sc, execs, stages
+    torch.cuda.empty_cache()
+    cross = None
+    if getattr(args, "cross_check", False):
+        # the same network through a DIFFERENT set of sliced labels and another tree (the plain-slicing search's plan,
+        # executed in stages as well), once, sharded over the same ranks: the two values must agree to 1e-3
+        cross = peps_cross_check(args, einstr, shapes, ops, labels, rank, world, local_rank, backend, dev,
+                                 float(t_hat), float(log_scale))
+        torch.cuda.empty_cache()
     if rank != 0:
         return None
 
     value = args.steps / elapsed
     # work of one contraction over ALL ranks: every stage's plan x its evaluations (a staged plan evaluates a stage
     # once per joint value of the sliced labels it depends on; plain slicing: one stage, once per slice)
-    sizes = sc.sizes
     n_eval_total = [int(x) for x in evals_all]
-    flop_sliced = float(sum(st[0].plan.flops * n for st, n in zip(stages, n_eval_total)))
+    flop_sliced = float(sum(sd.flops * n for sd, n in zip(stage_data, n_eval_total)))
     tflops = value * flop_sliced / 1e12
 
     # ---- roofline of the dominant kernel on rank 0 (per launch of R evaluations, HIP-event durations) ---------
     # algorithmic bytes of a step: both operands and the output once, from the step's own einsum string
     by_kernel, dump = {}, []
-    for k_, ((bc_, n_loc, R_, chunks_), ms_) in enumerate(zip(stages, stage_ms)):
-        infos = bc_.plan.step_infos()
-        tiles = bc_.executor.step_tiles()
-        for s_, (info, c) in enumerate(zip(infos, bc_.contract_list)):
-            lhs, out = c[2].split("->")
+    for k_, (sd, ms_) in enumerate(zip(stage_data, stage_ms)):
+        infos, tiles, R_, chunks_ = sd.infos, sd.tiles, sd.R, sd.launches
+        for s_, (info, step_str) in enumerate(zip(infos, sd.step_strs)):
+            lhs, out = step_str.split("->")
             nbytes = 4 * sum(int(np.prod([sizes[x] for x in set(t)])) if t else 1 for t in lhs.split(",") + [out])
             key = (info["kernel"], info["mode_a"], info["mode_b"], tiles[s_][0], tiles[s_][1])
             d = by_kernel.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
@@ -659,8 +688,7 @@ def run_peps(args, world, rank, local_rank, backend, dev):
             d["bytes"] += nbytes * R_ * chunks_
             d["launches"] += chunks_
             dump.append(dict(info, stage=k_, ms=float(ms_[s_]), bytes=nbytes, replicas=R_, launches=chunks_,
-                             tile=list(tiles[s_]), einsum=c[2]))
-    plan = stages[-1][0].plan
+                             tile=list(tiles[s_]), einsum=step_str))
     if args.dump_steps:
         with open(args.dump_steps, "w") as fh:
             json.dump(dump, fh)
@@ -714,22 +742,22 @@ def run_peps(args, world, rank, local_rank, backend, dev):
         "dtype": "f32",
         "data": "synthetic (standard normal / sqrt(D), NumPy default_rng(6), identical on every rank)",
         "config": {
-            "workload": f"peps_{rows}x{cols}_D{bond}_d2_sliced{sc.n_total}",
-            "slices": sc.n_total,
-            "slices_per_gpu": len(sc.my_slices),
+            "workload": f"peps_{rows}x{cols}_D{bond}_d2_sliced{n_total}",
+            "slices": n_total,
+            "slices_per_gpu": n_mine,
             "sliced_labels": len(labels),
-            "slices_in_flight_per_launch": sc.R,
-            "outer_labels_walked_on_the_host": getattr(sc, "outer", 0),
+            "slices_in_flight_per_launch": sc_R,
+            "outer_labels_walked_on_the_host": sc_outer,
+            "labels_the_root_stage_sums_itself": sc_unsliced,
             "execution": ("staged: a stage of the tree is evaluated once per joint value of the sliced labels below it "
                           "(dist.StagedSlicedContraction)" if staged else "plain: every slice repeats the whole path"),
-            "stages": [{"depends_on_sliced_labels": len(sc.stage_desc[k]["dep"]) if staged else len(labels),
-                        "evaluations": n_eval_total[k], "evaluations_on_rank0": stages[k][1], "steps": stages[k][0].plan.n_steps,
-                        "flop_per_evaluation": stages[k][0].plan.flops} for k in range(len(stages))],
+            "stages": [{"depends_on_sliced_labels": sd.dep, "evaluations": n_eval_total[k], "evaluations_on_rank0": sd.evaluated,
+                        "steps": sd.n_steps, "flop_per_evaluation": sd.flops} for k, sd in enumerate(stage_data)],
             "work_overhead_vs_unsliced": round(rep["work_overhead"], 3),
             "work_overhead_if_every_slice_repeated_everything": round(rep.get("plain_overhead", rep["work_overhead"]), 3),
             "largest_intermediate_elements": rep["largest_intermediate"],
             "unsliced_largest_intermediate_elements": rep["unsliced_largest_intermediate"],
-            "steps_per_slice": plan.n_steps if not staged else sum(st_[0].plan.n_steps for st_ in stages),
+            "steps_per_slice": sum(sd.n_steps for sd in stage_data),
             "flop_per_contraction_sliced": flop_sliced,
             "multiply_adds_unsliced_path": rep["unsliced_flops"],
             "slice_search_s": round(search_s, 2),
@@ -740,16 +768,41 @@ def run_peps(args, world, rank, local_rank, backend, dev):
         "roofline": roofline,
         "device": dict(device_info(dev), **under_load),
     }
-    if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = peps_cpu_baseline(sc, einstr, ops, labels, path, args.cpu_seconds)
+    if cpu_check is not None:
+        result["cpu_baseline"] = cpu_check
         if rep["unsliced_largest_intermediate"] <= 2 ** 28:
             result["unsliced_check"] = peps_unsliced_check(einstr, shapes, ops, float(t_hat), float(log_scale), local_rank)
+    if cross is not None:
+        result["cross_check"] = cross
     if getattr(args, "single_gpu_reference", False):
-        del sc, execs, stages
-        torch.cuda.empty_cache()
         result["strong_scaling"] = peps_single_gpu_reference(args, einstr, shapes, ops, labels, path, rep, local_rank,
                                                              world, elapsed / args.steps, float(t_hat), float(log_scale))
     return result
+
+
+def peps_cross_check(args, einstr, shapes, ops, labels, rank, world, local_rank, backend, dev, t_hat, log_scale):
+    """One more contraction of the same network on another slicing - the labels and tree of `dist.sliced_plan` (the
+    plain-slicing search: other labels than the staged plan's) - sharded over the same ranks; rank 0 reports the value
+    and its distance from the main run's."""
+    import torch.distributed as dist
+
+    from contractn_amd import dist as cdist
+
+    box = [None]
+    if rank == 0:
+        box[0] = cdist.sliced_plan(einstr, shapes, min_slices=args.slices, max_intermediate=args.max_intermediate)
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    labels2, path2, rep2 = box[0]
+    sc2 = cdist.StagedSlicedContraction(einstr, ops, labels2, optimize=path2, rank=rank, world=world, device=local_rank,
+                                        workspace_budget=int(args.workspace_gib * 2 ** 30))
+    t0 = time.perf_counter()
+    t2, c2 = sc2.run()
+    sec = time.perf_counter() - t0
+    return {"sliced_labels": len(labels2), "slices": sc2.n_total, "labels_shared_with_the_main_plan": len(set(labels2) & set(labels)),
+            "t_hat": float(t2), "log_scale": float(c2), "abs_log_diff": abs(float(c2) - log_scale),
+            "ok": bool(float(t2) == t_hat and abs(float(c2) - log_scale) <= 1e-3), "tolerance_abs_log": 1e-3,
+            "seconds": round(sec, 3)}
 
 
 def peps_single_gpu_reference(args, einstr, shapes, ops, labels, path, rep, device, world, sec_per_step, t_hat, log_scale):

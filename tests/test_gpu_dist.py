@@ -316,7 +316,7 @@ def test_bench_starts_its_own_ranks_and_reports_the_best_single_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "peps", "--rows", "4", "--cols", "4",
-           "--bond", "4", "--slices", "8", "--steps", "3", "--warmup", "2", "--single-gpu-reference"]
+           "--bond", "4", "--slices", "8", "--steps", "3", "--warmup", "2", "--single-gpu-reference", "--cross-check"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -324,6 +324,7 @@ def test_bench_starts_its_own_ranks_and_reports_the_best_single_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     assert line["config"]["slices_per_gpu"] * 2 == line["config"]["slices"]
+    assert line["cross_check"]["ok"] is True and line["cross_check"]["slices"] >= 8     # another slicing, the same value
     ss = line["strong_scaling"]
     assert ss["n_gpus"] == 2 and ss["sliced_single_gpu_agrees"] is True and ss["unsliced_single_gpu_agrees"] is True
     assert ss["best_single_gpu_ms"] == min(ss["sliced_single_gpu_ms"], ss["unsliced_single_gpu_ms"])
