@@ -423,12 +423,20 @@ def run_mps(args, world, rank, local_rank, backend, dev):
     # ---- roofline of the dominant kernel (per launch, HIP-event durations) ---------------
     by_kernel = {}
     tiles = ex.step_tiles()   # what the launcher actually ran (it may retile by replica count)
+    pending, pending_bytes, zip_bytes = 0.0, 0.0, {}
     for s, info in enumerate(infos):
+        if tiles[s] == (1, 1):      # the first step of a zipper pair: it runs inside the next step's launch (k_zip_f32)
+            pending += info["flops"] * Rg
+            pending_bytes += esz * Rg * info["batch"] * (info["m"] * info["k"] + info["k"] * info["n"])   # E and X once
+            continue
         key = (info["kernel"], info["mode_a"], info["mode_b"], tiles[s][0], tiles[s][1])
         d = by_kernel.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
         d["ms"] += step_ms_last[s]
-        d["flops"] += info["flops"] * Rg
+        d["flops"] += info["flops"] * Rg + pending
         d["launches"] += 1
+        if pending:                 # ... Y once, E' once; T never reaches memory
+            zip_bytes[key] = pending_bytes + esz * Rg * info["batch"] * (info["k"] * info["n"] + info["m"] * info["n"])
+        pending, pending_bytes = 0.0, 0.0
     dom_key = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
     dom = by_kernel[dom_key]
     from contractn_amd.engine import KERNEL_NAMES
@@ -443,6 +451,8 @@ def run_mps(args, world, rank, local_rank, backend, dev):
                     if (info["kernel"], info["mode_a"], info["mode_b"], tiles[s_][0], tiles[s_][1]) == dom_key)
     alg_bytes = esz * Rg * dom_info["batch"] * (dom_info["m"] * dom_info["k"] + dom_info["k"] * dom_info["n"]
                                                 + dom_info["m"] * dom_info["n"])
+    if dom_key in zip_bytes:
+        alg_bytes = zip_bytes[dom_key]
     roofline = {
         "bound": "mfma",
         "kernel": kernel_label(dom_key),
@@ -1053,6 +1063,8 @@ def kernel_label(key):
     from contractn_amd.engine import KERNEL_NAMES
 
     kind, ma, mb, tm, tn = key
+    if kind == 2 and tm == 512:
+        return "k_zip_f32 (two zipper GEMM steps per launch: T = E.psi stays in registers, E' = T.phi; 128 x 256 outputs per workgroup)"
     if kind == 2 and tm == 256:
         return f"k_mfma_f32_g<{'8' if tn == 256 else '4'},2,asm,{ma},{mb}> ({tm}x{tn} tiles, LDS-DMA ring)"
     if kind == 3 and tn == 128:

@@ -31,6 +31,7 @@
 #include "kernels_mfma_g.h"
 #include "kernels_mfma_g64.h"
 #include "kernels_mfma_h.h"
+#include "kernels_zip.h"
 #include "kernels_mfma_lat.h"
 #include "kernels_stream.h"
 
@@ -57,6 +58,7 @@ struct DevSwitches {
   int splitk_max = 0;    // CTN_SPLITK_MAX: tile-count threshold of the latency mode
   int lat = -1;          // CTN_LAT: 0 never use the one-launch latency form (k_mfma_f32_lat), 1 whenever the shape allows (tests)
   int hform = -1;        // CTN_H: 0 never use the one-tile-per-CU form (k_mfma_f32_h), 1 whenever the shape allows (tests)
+  int zip = -1;          // CTN_ZIP: 0 never fuse a zipper's two GEMM steps into one launch (k_zip_f32), 1 whenever the pair matches (tests)
   bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
   const char* stamps = nullptr;  // CTN_DEBUG_STAMPS=<file> (make STAMPS=1 builds): dump in-kernel cycle stamps
   int stamp_step = -1;   // CTN_DEBUG_STAMP_STEP=<s>: stamp only this step
@@ -72,6 +74,7 @@ static DevSwitches read_dev_switches() {
   d.splitk_max = num("CTN_SPLITK_MAX", 0);
   d.lat = num("CTN_LAT", -1);
   d.hform = num("CTN_H", -1);
+  d.zip = num("CTN_ZIP", -1);
   d.lat64_min_k = num("CTN_LAT64_MIN_K", 512);
   d.splitk_fill_long = num("CTN_SPLITK_FILL_LONG", 2);
   d.lat_max_t = num("CTN_LAT_MAX_T", 64);
@@ -122,6 +125,11 @@ struct Exec {
   bool graph_warm = false;          // one eager enqueue has run (code objects loaded, tiles recorded)
   bool graph_aligned = true;        // outs_aligned16 the graph was captured under
   hipGraphExec_t graph_exec = nullptr;
+  // zipper pairs (kernels_zip.h): zip[s2] describes the fused launch of steps (s2 - 1, s2); zip_skip[s1] = the first
+  // step of such a pair is never launched (its result only exists in the fused kernel's registers)
+  struct ZipDesc { bool on = false; int64_t ldE = 0, ldXq = 0, ldXk = 0, ldYq = 0, ldYm = 0, ldC = 0; int Q = 0, U = 0, K1 = 0; };
+  std::vector<ZipDesc> zip;
+  std::vector<char> zip_skip;
   std::vector<int32_t> launched_tile;  // per step: (tile rows << 16 | tile columns) of the last enqueue's MFMA kernel, else 0
   char* d_ws = nullptr;
   int32_t* d_tables = nullptr;
@@ -486,6 +494,59 @@ static void launch_splitk_reduce(Exec* E, int partials, int R, const StepArgs& a
   hipLaunchKernelGGL(k_splitk_reduce<T>, dim3(partials, R), dim3(256), 0, E->stream, a, sk);
 }
 
+// Do steps (s2 - 1, s2) form a zipper pair that k_zip_f32 can run as one launch?  Checked on the plan's own offset
+// tables (every operand dense along its innermost index with uniform strides), so nothing about the network's labels
+// is assumed: T = E . X with |m1| = 256 rows from E, columns (q, u) from X; E' = T . Y contracting (m1, q), |n2| = 256.
+static bool zip_match(const Plan& P, int s2, Exec::ZipDesc* z) {
+  if (s2 < 1 || s2 + 1 >= P.n_steps || P.dtype != CTN_F32) return false;
+  const Step& a = P.steps[s2 - 1];
+  const Step& b = P.steps[s2];
+  auto plain = [&](const Step& st) {
+    return st.kernel == CTN_KERNEL_MFMA_F32 && st.Bt == 1 && st.rhs >= 0 && st.lhs2 < 0 && !st.epw && st.modeA == 1 &&
+           st.modeB == 1 && !st.collapse;
+  };
+  if (!plain(a) || !plain(b) || b.lhs != a.out || !b.cvec) return false;
+  if (a.rhs >= P.n_inputs || b.rhs >= P.n_inputs) return false;            // X and Y: network inputs (scale 1)
+  if (a.M != ZM || b.N != ZM || a.K % ZK != 0 || a.K < 2 * ZK || a.N % ZU != 0) return false;
+  const int32_t* T = P.tables.data();
+  const int32_t *omA = T + a.t.omA, *okA = T + a.t.okA, *onB = T + a.t.onB, *okB = T + a.t.okB, *omC = T + a.t.omC, *onC = T + a.t.onC;
+  const int64_t N1 = a.N;
+  for (int i = 0; i < ZM; ++i) if (omA[i] != i || omC[i] != (int64_t)i * N1) return false;     // E rows dense, T = [m1][N1]
+  for (int64_t n = 0; n < N1; ++n) if (onC[n] != n) return false;
+  int64_t U = N1;
+  for (int64_t n = 1; n < N1; ++n) if (onB[n] != onB[0] + n) { U = n; break; }
+  if (onB[0] != 0 || U % ZU != 0 || N1 % U != 0) return false;
+  const int64_t Q = N1 / U, ldXq = Q > 1 ? onB[U] : 0;
+  for (int64_t n = 0; n < N1; ++n) if (onB[n] != (n / U) * ldXq + n % U) return false;
+  const int64_t ldE = okA[1] - okA[0], ldXk = okB[1] - okB[0];
+  for (int64_t k = 0; k < a.K; ++k) if (okA[k] != k * ldE || okB[k] != k * ldXk) return false;
+  if (ldE < ZM || b.M != U || b.K != (int64_t)ZM * Q) return false;
+  const int32_t *omA2 = T + b.t.omA, *okA2 = T + b.t.okA, *onB2 = T + b.t.onB, *okB2 = T + b.t.okB, *omC2 = T + b.t.omC, *onC2 = T + b.t.onC;
+  for (int64_t u = 0; u < U; ++u) if (omA2[u] != u) return false;                                   // T dense along u
+  for (int i = 0; i < ZM; ++i) if (onB2[i] != i || onC2[i] != i) return false;
+  const int64_t ldC = U > 1 ? omC2[1] - omC2[0] : ZM;
+  for (int64_t u = 0; u < U; ++u) if (omC2[u] != u * ldC) return false;
+  if (ldC < ZM) return false;
+  // the contracted group of the second step enumerates (m1, q) in some order: read each entry's (m1, q) off T's offset
+  int64_t ldYm = -1, ldYq = Q > 1 ? -1 : 0;
+  for (int64_t k = 0; k < b.K; ++k) {
+    const int64_t off = okA2[k], m1 = off / N1, q = (off % N1) / U;
+    if (off % U != 0 || m1 >= ZM) return false;
+    if (m1 == 1 && q == 0) ldYm = okB2[k];
+    if (m1 == 0 && q == 1) ldYq = okB2[k];
+  }
+  if (ldYm < ZM || ldYq < 0) return false;
+  std::vector<char> seen((size_t)b.K, 0);
+  for (int64_t k = 0; k < b.K; ++k) {
+    const int64_t off = okA2[k], m1 = off / N1, q = (off % N1) / U;
+    if (okB2[k] != q * ldYq + m1 * ldYm || seen[(size_t)(m1 * Q + q)]) return false;
+    seen[(size_t)(m1 * Q + q)] = 1;
+  }
+  z->on = true; z->ldE = ldE; z->ldXq = ldXq; z->ldXk = ldXk; z->ldYq = ldYq; z->ldYm = ldYm; z->ldC = ldC;
+  z->Q = (int)Q; z->U = (int)U; z->K1 = (int)a.K;
+  return true;
+}
+
 static int exec_launch_steps(Exec* E) {
   const Plan& P = *E->plan;
   const int R = E->R;
@@ -519,6 +580,61 @@ static int exec_launch_steps(Exec* E) {
         continue;
       }
       collect_left = G.len; collect_head = s;   // first time: the steps' arguments are built below, not launched
+    }
+    if (!E->zip_skip.empty() && E->zip_skip[s]) {   // first step of a zipper pair: runs inside the next step's launch
+      if ((int)E->launched_tile.size() != P.n_steps) E->launched_tile.assign(P.n_steps, 0);
+      E->launched_tile[s] = (1 << 16) | 1;          // marker: absorbed into the next launched step
+      if (E->timing_runs < E->timing_slots) {
+        const size_t e0 = ((size_t)E->timing_runs * P.n_steps + s) * 2;
+        HIPCHECK(hipEventRecord(E->events[e0], E->stream));
+        HIPCHECK(hipEventRecord(E->events[e0 + 1], E->stream));
+      }
+      continue;
+    }
+    if (!E->zip.empty() && E->zip[s].on) {
+      const Exec::ZipDesc& zd = E->zip[s];
+      const Step& s1 = P.steps[s - 1];
+      ZipArgs z{};
+      z.ptrs = E->d_ptrs; z.n_tensors = E->n_tensors;
+      z.idE = s1.lhs; z.idX = s1.rhs; z.idY = st.rhs; z.idC = st.out;
+      z.ldE = zd.ldE; z.ldXq = zd.ldXq; z.ldXk = zd.ldXk; z.ldYq = zd.ldYq; z.ldYm = zd.ldYm; z.ldC = zd.ldC;
+      z.K1 = zd.K1; z.Q = zd.Q; z.U = zd.U;
+      z.partE = nullptr; z.PE = 0; z.strideE = 0; z.numelE = 1.0;
+      if (s1.lhs >= P.n_inputs && P.stabilize && !E->eager_rescale && P.steps[P.tensors[s1.lhs].producer].kernel != CTN_KERNEL_FUSED) {
+        const int ps = P.tensors[s1.lhs].producer;
+        z.partE = E->d_partials + (size_t)E->step_off[ps] * R;
+        z.PE = z.strideE = E->step_partials[ps];
+        z.numelE = (double)P.tensors[s1.lhs].numel;
+      }
+      z.min_norm = P.min_norm;
+      z.partC = E->d_partials + (size_t)E->step_off[s] * R;
+      z.partC_stride = E->step_partials[s];
+      z.R = R; z.dbg = nullptr;
+      const bool timed_z = E->timing_runs < E->timing_slots;
+      const size_t ez = timed_z ? ((size_t)E->timing_runs * P.n_steps + s) * 2 : 0;
+      if (timed_z) HIPCHECK(hipEventRecord(E->events[ez], E->stream));
+      if ((int)E->launched_tile.size() != P.n_steps) E->launched_tile.assign(P.n_steps, 0);
+      E->launched_tile[s] = (512 << 16) | 256;      // the fused pair: 128 values of u x all 256 n2 per workgroup
+      const int per = zd.U / ZU;
+      if (E->sw.stamps && (E->sw.stamp_step < 0 || E->sw.stamp_step == s)) {
+        const size_t need = (size_t)per * R;
+        if (E->dbg_tiles < need) {
+          if (E->d_dbg) (void)hipFree(E->d_dbg);
+          HIPCHECK(hipMalloc((void**)&E->d_dbg, need * 64));
+          E->dbg_tiles = need;
+        }
+        z.dbg = E->d_dbg;
+        HIPCHECK(hipMemsetAsync(E->d_dbg, 0, E->dbg_tiles * 64, E->stream));
+      }
+      hipLaunchKernelGGL(k_zip_f32, dim3((unsigned)((int64_t)per * R)), dim3(512), 0, E->stream, z);
+      if (E->eager_rescale && P.stabilize && s + 1 < P.n_steps) {
+        const int64_t numel = P.tensors[st.out].numel;
+        const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / 4 + 255) / 256, 2048)), R);
+        hipLaunchKernelGGL(k_renorm<float>, g, dim3(256), 0, E->stream, (void* const*)E->d_ptrs, E->n_tensors, st.out, numel,
+                           (const double*)z.partC, E->step_partials[s], E->step_partials[s], P.min_norm);
+      }
+      if (timed_z) HIPCHECK(hipEventRecord(E->events[ez + 1], E->stream));
+      continue;
     }
     if (st.kernel == CTN_KERNEL_FUSED) {   // formed on the fly inside its consumer: nothing to launch
       if (E->timing_runs < E->timing_slots) {
@@ -1188,6 +1304,30 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     E.step_off[s] = E.part_slots;
     E.part_slots += E.step_partials[s];
   }
+  // zipper pairs: at least one full round of workgroups (each is 134 MFLOP long), or CTN_ZIP=1
+  if (!P.chain && E.sw.zip != 0) {
+    E.zip.assign(P.n_steps, Exec::ZipDesc());
+    E.zip_skip.assign(P.n_steps, 0);
+    bool any = false;
+    for (int s = 1; s + 1 < P.n_steps; ++s) {
+      Exec::ZipDesc z;
+      if (E.zip_skip[s - 1] || (s >= 2 && E.zip[s - 1].on) || !zip_match(P, s, &z)) continue;
+      if (E.sw.zip != 1 && (int64_t)(z.U / ZU) * replicas < E.n_cu) continue;
+      E.zip[s] = z;
+      E.zip_skip[s - 1] = 1;
+      any = true;
+      // one abs-sum partial per workgroup of the fused launch; the skipped step keeps its (never written, zero) slots
+      E.part_slots -= E.step_partials[s];
+      E.step_partials[s] = z.U / ZU;
+      E.part_slots += E.step_partials[s];
+    }
+    if (any) {   // regions moved: lay the offsets out again
+      E.part_slots = 0;
+      for (int s = 0; s < P.n_steps; ++s) { E.step_off[s] = E.part_slots; E.part_slots += E.step_partials[s]; }
+    } else {
+      E.zip.clear(); E.zip_skip.clear();
+    }
+  }
   // leaf groups: runs of consecutive plain streaming steps on network inputs, same kernel variant (see Exec::LeafGroup)
   if (!P.chain && E.sw.group) {
     E.groups.assign(P.n_steps, Exec::LeafGroup());
@@ -1334,7 +1474,10 @@ static bool exec_scales_suspect(const Exec* E, const double* resc = nullptr, int
         return v == 0.0 ? 1.0 : v;
       };
       if (st.kernel == CTN_KERNEL_FUSED) continue;
-      const double sab = scale_of(st.lhs) * (st.rhs >= 0 ? scale_of(st.rhs) : 1.0) * (st.lhs2 >= 0 ? scale_of(st.lhs2) : 1.0);
+      if (!E->zip_skip.empty() && E->zip_skip[s]) continue;          // runs inside the next step's launch
+      double sab = scale_of(st.lhs) * (st.rhs >= 0 ? scale_of(st.rhs) : 1.0) * (st.lhs2 >= 0 ? scale_of(st.lhs2) : 1.0);
+      if (!E->zip.empty() && E->zip[s].on)                           // the fused pair accumulates on E, X and Y as stored
+        sab = scale_of(P.steps[s - 1].lhs) * scale_of(P.steps[s - 1].rhs) * scale_of(st.rhs);
       const double so = rs[s];
       if (!std::isfinite(so) || !std::isfinite(sab)) return true;
       if (so == 0.0) { if (sab > zhi || sab < zlo) return true; continue; }
