@@ -341,8 +341,8 @@ static bool h_forced(const Step& st, int dtype, const DevSwitches& sw) {
 }
 
 // One-tile-per-CU form (k_mfma_f32_h, kernels_mfma_h.h): 128 x 128 tiles, K split over the two halves of an 8-wave
-// workgroup.  Taken when the step's 128 x 128 tiles are about one round of one workgroup per CU - between half a chip
-// and a whole one - which is where the register-staged kernel's 128 x 64 tiles run as a single round of two small
+// workgroup.  Taken when the step's 128 x 128 tiles are about one round of one workgroup per CU - between three quarters
+// of a chip and a whole one - which is where the register-staged kernel's 128 x 64 tiles run as a single round of two small
 // workgroups per CU and the large-tile kernel would leave CUs idle (one MPS site applied to 4096 inputs: 256 tiles).
 static bool h_form(const Plan& P, const Step& st, int R, int n_cu, int dtype, const DevSwitches& sw, bool c_vec) {
   if (sw.hform == 0 || dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.rhs < 0 || st.collapse) return false;
@@ -354,7 +354,9 @@ static bool h_form(const Plan& P, const Step& st, int R, int n_cu, int dtype, co
   if (t128 > kMaxPartials) return false;
   if (sw.hform == 1) return true;
   if (sw.mfma_g >= 2 && st.tileM == 256) return false;     // tests that force the large-tile kernels
-  return 2 * t128 * R >= n_cu && t128 * R <= n_cu;
+  // (from three quarters of a chip of tiles: at half a chip - 8 networks of the headline in flight, 2048 inputs through
+  // the batched MPS - the smaller tiles of the other forms keep more CUs busy: 27.1 vs 20.6 us per site at B = 2048)
+  return 4 * t128 * R >= 3 * n_cu && t128 * R <= n_cu;
 }
 
 // Tile of the register-staged fp32 kernel for this step and replica count: the planner's 128 / 64 choice, halved
