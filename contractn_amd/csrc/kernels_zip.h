@@ -53,7 +53,9 @@ struct ZipArgs {
   unsigned long long* dbg;  // CTN_STAMPS builds only
 };
 
-constexpr int ZM = 256, ZU = 128, ZK = 16, ZST = 3, ZSTG = 8192;   // stage: 8192 floats = 32 KiB
+constexpr int ZM = 256, ZU = 128, ZK = 16, ZSTG = 8192;   // stage: 8192 floats = 32 KiB
+constexpr bool ZPF = (CTN_EXP & 1) != 0;      // experiment: the first fragments of a tile are read at the end of the tile before
+constexpr int ZST = (CTN_EXP & 2) ? 4 : 3;    // experiment: ring depth
 
 __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[ZST * ZSTG + 16];
@@ -84,23 +86,40 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
   constexpr int T2 = (ZM / 2) / ZK;            // phase-2 tiles per q: 16 rows of each m1 half at a time
   const int TQ = T1 + T2, TT = a.Q * TQ;
 
-  // the LDS-DMA requests of tile t (this wave's share): phase 1: rows 2 w, 2 w + 1 of E (1 KiB each) and of Xq (both in
-  // one request: lanes 0-31 / 32-63); phase 2: rows 4 ub .. 4 ub + 3 of this wave's m1 half of Yq
-  auto request = [&](int t, int stage) {
+  // the LDS-DMA requests of the next tile not yet asked for (this wave's share): phase 1: rows 2 w, 2 w + 1 of E (1 KiB
+  // each) and of Xq (both in one request: lanes 0-31 / 32-63); phase 2: rows 4 ub .. 4 ub + 3 of this wave's m1 half of
+  // Yq.  The cursor walks the tiles in order with running pointers - a handful of scalar adds per request: both waves
+  // of a SIMD come out of the tile's barrier together, and whatever they do before their next MFMA is matrix-pipe idle
+  // time (~100 scalar instructions of index arithmetic here cost 8 % of the kernel).
+  // (the pointers are wave-uniform - scalar registers; a lane's own offset is a 32-bit number added by the instruction)
+  const float* const rE0 = E + (int64_t)(2 * w) * a.ldE;
+  const float* rE = rE0;
+  const float* rX = X + (int64_t)(2 * w) * a.ldXk;
+  const float* rY = Y + (int64_t)(kh * (ZM / 2) + 4 * ub) * a.ldYm;
+  const int offE = 4 * lane, offX = h * (int)a.ldXk + 4 * l31;
+  const int64_t stepE = (int64_t)ZK * a.ldE, stepX = (int64_t)ZK * a.ldXk, stepY = (int64_t)ZK * a.ldYm;
+  const int64_t nextX = a.ldXq - (int64_t)a.K1 * a.ldXk, nextY = a.ldYq - (int64_t)(ZM / 2) * a.ldYm;
+  int rq_s = 0, rq_left = TT;
+  auto request_issue = [&](int stage) {
     float* st = smem + stage * ZSTG;
-    const int q = t / TQ, s = t - q * TQ;
-    if (s < T1) {
-      const int k0 = s * ZK + 2 * w;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        glds16(E + (int64_t)(k0 + i) * a.ldE + 4 * lane, st + (2 * w + i) * ZM);
-      glds16(X + (int64_t)q * a.ldXq + (int64_t)(k0 + h) * a.ldXk + 4 * l31, st + 4096 + (2 * w) * ZU);
+    if (rq_s < T1) {
+      glds16(rE + offE, st + (2 * w) * ZM);
+      glds16(rE + a.ldE + offE, st + (2 * w + 1) * ZM);
+      glds16(rX + offX, st + 4096 + (2 * w) * ZU);
     } else {
-      const int m0 = kh * (ZM / 2) + (s - T1) * ZK + 4 * ub;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        glds16(Y + (int64_t)q * a.ldYq + (int64_t)(m0 + i) * a.ldYm + 4 * lane, st + kh * 4096 + (4 * ub + i) * ZM);
+      for (int i = 0; i < 4; ++i) glds16(rY + i * a.ldYm + offE, st + kh * 4096 + (4 * ub + i) * ZM);
     }
+  };
+  auto request_step = [&]() {                  // (plain selects: the running pointers stay in scalar registers)
+    const bool p1 = rq_s < T1;
+    --rq_left;
+    ++rq_s;
+    const bool wrap = rq_s == TQ;
+    rq_s = wrap ? 0 : rq_s;
+    rE = wrap ? rE0 : rE + (p1 ? stepE : 0);
+    rX += (p1 ? stepX : 0) + (wrap ? nextX : 0);
+    rY += (p1 ? 0 : stepY) + (wrap ? nextY : 0);
   };
 
   f32x16 acc1[4], acc2[8];
@@ -113,8 +132,11 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
 
-  request(0, 0);
-  request(1, 1);
+#pragma unroll
+  for (int i = 0; i < ZST - 1; ++i) {
+    request_issue(i);
+    request_step();
+  }
   double pve = 0.0;
   if (a.partE) {
     const double* __restrict__ pr = a.partE + (size_t)r * a.strideE;
@@ -132,30 +154,53 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
   // (measured without gain, LAB_NOTES R3: s_setprio 1 for waves 4-7; those waves taking the barrier at the END of a
   // tile so that the two waves of a SIMD run half a tile apart: -0.8 %)
   constexpr int bar_at = 3;
-  int st_cur = 0, st_nxt = 1, st_req = 2, t = 0;
+  int st_cur = 0, st_nxt = 1, st_req = ZST - 1, t = 0;
+#ifdef CTN_STAMPS
+  unsigned long long wait_vm = 0, wait_bar = 0;
+#endif
   auto middle = [&]() {                        // the barrier of a tile, in the middle of its MFMA phase
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): tile t + 1 - this wave's requests, a tile old
+#ifdef CTN_STAMPS
+    const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#endif
+    // tile t + 1 has landed: this wave's requests, a tile old (ring of 4: two tiles old, tile t + 2's may be in flight)
+    if (ZST == 4 && t + 2 < TT) __builtin_amdgcn_s_waitcnt(0x0F73);
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef CTN_STAMPS
+    const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < TT) request(t + 2, st_req);
+#ifdef CTN_STAMPS
+    const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+    wait_vm += s1 - s0;
+    wait_bar += s2 - s1;
+#endif
+    if (rq_left > 0) request_issue(st_req);
     __builtin_amdgcn_sched_barrier(0);
   };
   auto advance = [&]() {
+    st_req = st_cur;
     st_cur = st_nxt;
-    st_nxt = st_req;
-    st_req = st_req == ZST - 1 ? 0 : st_req + 1;
+    st_nxt = st_nxt == ZST - 1 ? 0 : st_nxt + 1;
     ++t;
   };
+  float fa[2][4], fb[2], fy[2][8];
+  if (ZPF) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[0][i] = smem[h * ZM + kh * (ZM / 2) + l31 + 32 * i];
+    fb[0] = smem[4096 + h * ZU + ub * 32 + l31];
+  }
 
   for (int q = 0; q < a.Q; ++q) {
     // ---- phase 1: Tq[m1 half kh, u-block ub] = sum_k1 E[k1][m1] Xq[k1][u] ------------------------------------
     for (int s = 0; s < T1; ++s) {
       const float* cA = smem + st_cur * ZSTG + h * ZM + kh * (ZM / 2) + l31;       // E image [k1][256]
       const float* cB = smem + st_cur * ZSTG + 4096 + h * ZU + ub * 32 + l31;      // Xq image [k1][128]
-      float fa[2][4], fb[2];
+      if (!ZPF) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[0][i] = cA[32 * i];
-      fb[0] = cB[0];
+        for (int i = 0; i < 4; ++i) fa[0][i] = cA[32 * i];
+        fb[0] = cB[0];
+      }
 #pragma unroll
       for (int kk = 0; kk < ZK / 2; ++kk) {
         const int c = kk & 1, nx = c ^ 1;
@@ -163,13 +208,28 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) fa[nx][i] = cA[2 * (kk + 1) * ZM + 32 * i];
           fb[nx] = cB[2 * (kk + 1) * ZU];
+        } else if (ZPF) {                        // the next tile (landed: this tile's barrier is behind us): its first fragments
+          const float* nS = smem + st_nxt * ZSTG;
+          if (s + 1 < T1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[0][i] = nS[h * ZM + kh * (ZM / 2) + l31 + 32 * i];
+            fb[0] = nS[4096 + h * ZU + ub * 32 + l31];
+          } else {
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) fy[0][nb] = nS[kh * 4096 + (4 * h) * ZM + l31 + 32 * nb];
+          }
         }
+        if (kk == bar_at + 1) request_step();   // the cursor moves on in the shadow of this k-step's MFMAs
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c], acc1[i], 0, 0, 0);   // D1[m1][u]
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
         if (kk == bar_at) middle();
       }
       advance();
@@ -179,23 +239,39 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
     for (int ms = 0; ms < T2; ++ms) {
       // rows 16 ms .. 16 ms + 15 of the half = half of accumulator block ms / 2: its register groups g = 2 (ms & 1), + 1
       const float* cY = smem + st_cur * ZSTG + kh * 4096 + (4 * h) * ZM + l31;      // Yq image [16 rows][256]
-      float fy[2][8];
+      if (!ZPF) {
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb) fy[0][nb] = cY[32 * nb];
+        for (int nb = 0; nb < 8; ++nb) fy[0][nb] = cY[32 * nb];
+      }
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {           // k-step (g, e) = (kk / 4, kk % 4): row 8 (kk / 4) + 4 h + e of the tile
         const int c = kk & 1, nx = c ^ 1;
         if (kk + 1 < 8) {
 #pragma unroll
           for (int nb = 0; nb < 8; ++nb) fy[nx][nb] = cY[(8 * ((kk + 1) / 4) + (kk + 1) % 4) * ZM + 32 * nb];
+        } else if (ZPF) {
+          const float* nS = smem + st_nxt * ZSTG;
+          if (ms + 1 < T2) {
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) fy[0][nb] = nS[kh * 4096 + (4 * h) * ZM + l31 + 32 * nb];
+          } else if (t + 1 < TT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[0][i] = nS[h * ZM + kh * (ZM / 2) + l31 + 32 * i];
+            fb[0] = nS[4096 + h * ZU + ub * 32 + l31];
+          }
         }
         const float tq = acc1[ms / 2][4 * (2 * (ms & 1) + kk / 4) + kk % 4];
+        if (kk == bar_at + 1) request_step();
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb)
           acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fy[c][nb], tq, acc2[nb], 0, 0, 0);       // D2^T[n2][u]
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
         if (kk == bar_at) middle();
       }
       advance();
@@ -206,7 +282,12 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
       for (int e = 0; e < 16; ++e) acc1[i][e] = 0.f;
   }
 #ifdef CTN_STAMPS
-  if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 2] = __builtin_amdgcn_s_memtime();
+  if (a.dbg && tid == 0) {
+    a.dbg[(size_t)pid * 8 + 2] = __builtin_amdgcn_s_memtime();
+    a.dbg[(size_t)pid * 8 + 5] = wait_vm;
+    a.dbg[(size_t)pid * 8 + 6] = wait_bar;
+  }
+  if (a.dbg && tid == 448) a.dbg[(size_t)pid * 8 + 7] = wait_vm + wait_bar;
 #endif
 
   // ---- the two m1 halves meet: each partner hands over four of its eight n2 blocks (two rounds of two through the

@@ -30,4 +30,4 @@ else:
     med = lambda x: int(np.median(x))
     print("workgroups", len(a), "prologue", med(a[:, 1] - a[:, 0]), "main", med(a[:, 2] - a[:, 1]), "exchange", med(a[:, 4] - a[:, 2]),
           "epilogue", med(a[:, 3] - a[:, 4]), "total", med(a[:, 3] - a[:, 0]), "span", a[:, 3].max() - a[:, 0].min(),
-          "ideal main 524288")
+          "ideal main 524288", "wave0: vmcnt wait", med(a[:, 5]), "barrier wait", med(a[:, 6]), "wave7: both", med(a[:, 7]))
