@@ -32,6 +32,7 @@
 #include "kernels_mfma_g64.h"
 #include "kernels_mfma_h.h"
 #include "kernels_zip.h"
+#include "kernels_sweep.h"
 #include "kernels_mfma_lat.h"
 #include "kernels_stream.h"
 
@@ -58,6 +59,7 @@ struct DevSwitches {
   int splitk_max = 0;    // CTN_SPLITK_MAX: tile-count threshold of the latency mode
   int lat = -1;          // CTN_LAT: 0 never use the one-launch latency form (k_mfma_f32_lat), 1 whenever the shape allows (tests)
   int hform = -1;        // CTN_H: 0 never use the one-tile-per-CU form (k_mfma_f32_h), 1 whenever the shape allows (tests)
+  int sweep = -1;        // CTN_SWEEP: 0 never walk a chain of epilogue-summed steps in one launch (k_sweep_f32), 1 whenever one matches (tests)
   int zip = -1;          // CTN_ZIP: 0 never fuse a zipper's two GEMM steps into one launch (k_zip_f32), 1 whenever the pair matches (tests)
   bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
   const char* stamps = nullptr;  // CTN_DEBUG_STAMPS=<file> (make STAMPS=1 builds): dump in-kernel cycle stamps
@@ -75,6 +77,7 @@ static DevSwitches read_dev_switches() {
   d.lat = num("CTN_LAT", -1);
   d.hform = num("CTN_H", -1);
   d.zip = num("CTN_ZIP", -1);
+  d.sweep = num("CTN_SWEEP", -1);
   d.lat64_min_k = num("CTN_LAT64_MIN_K", 512);
   d.splitk_fill_long = num("CTN_SPLITK_FILL_LONG", 2);
   d.lat_max_t = num("CTN_LAT_MAX_T", 64);
@@ -130,6 +133,22 @@ struct Exec {
   struct ZipDesc { bool on = false; int64_t ldE = 0, ldXq = 0, ldXk = 0, ldYq = 0, ldYm = 0, ldC = 0; int Q = 0, U = 0, K1 = 0; };
   std::vector<ZipDesc> zip;
   std::vector<char> zip_skip;
+  // a sweep (kernels_sweep.h): a run of epilogue-summed GEMM steps, each on the result of the one before, walked by ONE
+  // launch at the position of its last member; sweep_role[s] = 1 a member that is never launched, 2 the last member
+  struct SweepDesc {
+    bool on = false;
+    std::vector<int> steps;          // the members' step indices, in chain order
+    int64_t ldIn = 0, ldOut = 0, ldWl = 0, ldWp = 0, ldX = 0;
+    int J = 0;
+  };
+  SweepDesc sweep;
+  std::vector<char> sweep_role;
+  int32_t* d_sweep_ids = nullptr;      // [S][2] tensor ids (W_s, x_s)
+  int64_t* d_sweep_off = nullptr;      // [S] step_off of the members
+  int32_t* d_sweep_slots = nullptr;    // [S] step_partials of the members
+  double* d_sweep_a = nullptr;         // [R][S][J]
+  float* d_sweep_s = nullptr;          // [R][S][J]
+  double* d_sweep_z = nullptr;         // [R][S]
   std::vector<int32_t> launched_tile;  // per step: (tile rows << 16 | tile columns) of the last enqueue's MFMA kernel, else 0
   char* d_ws = nullptr;
   int32_t* d_tables = nullptr;
@@ -186,7 +205,8 @@ struct Exec {
     for (void* p : {(void*)d_ws, (void*)d_tables, (void*)d_tables64, (void*)d_ptrs, (void*)d_partials, (void*)d_scratch, (void*)d_slab, (void*)d_slab2,
                     (void*)d_log, (void*)d_resc, (void*)d_logs, (void*)d_chain, d_ones, (void*)d_stepP, (void*)d_stepNumel,
                     (void*)d_stepOff, (void*)d_stepSlots,
-                    (void*)d_stage_in, (void*)d_stage_out, (void*)d_group_args})
+                    (void*)d_stage_in, (void*)d_stage_out, (void*)d_group_args, (void*)d_sweep_ids, (void*)d_sweep_off,
+                    (void*)d_sweep_slots, (void*)d_sweep_a, (void*)d_sweep_s, (void*)d_sweep_z})
       if (p) (void)hipFree(p);
     if (h_pack) (void)hipHostFree(h_pack);
     if (h_group_args) (void)hipHostFree(h_group_args);
@@ -549,6 +569,74 @@ static bool zip_match(const Plan& P, int s2, Exec::ZipDesc* z) {
   return true;
 }
 
+// Is step s an epilogue-summed GEMM step that k_sweep_f32 can take as one site of a sweep?  Checked on the plan's own
+// offset tables: E row-major [b][l], W[l][p][r] with r unit-stride, x[b][p] with p unit-stride, result rows [b][r].
+struct SweepShape { int64_t ldA = 0, ldC = 0, ldWl = 0, ldWp = 0, ldX = 0, M = 0; };
+static bool sweep_step_shape(const Plan& P, int s, SweepShape* sh) {
+  const Step& st = P.steps[s];
+  if (P.dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.epw != SWP || st.Bt != 1 || st.K != SWD ||
+      st.N != (int64_t)SWD * SWP || st.M % SWR != 0 || st.collapse || s + 1 >= P.n_steps)
+    return false;
+  if (st.rhs < 0 || st.rhs >= P.n_inputs || st.lhs2 < 0 || st.lhs2 >= P.n_inputs) return false;   // W, x: network inputs
+  const int32_t* T = P.tables.data();
+  const int32_t *omA = T + st.t.omA, *okA = T + st.t.okA, *onB = T + st.t.onB, *okB = T + st.t.okB, *omC = T + st.t.omC,
+                *onC = T + st.t.onC, *omX = T + st.t.omA2;
+  const int64_t M = st.M;
+  const int64_t ldA = M > 1 ? omA[1] : SWD, ldC = M > 1 ? omC[1] : SWD, ldX = M > 1 ? omX[1] : SWP, ldWl = okB[1];
+  for (int64_t m = 0; m < M; ++m)
+    if (omA[m] != m * ldA || omC[m] != m * ldC || omX[m] != m * ldX) return false;
+  for (int k = 0; k < SWD; ++k)
+    if (okA[k] != k || okB[k] != (int64_t)k * ldWl) return false;
+  int64_t ldWp = INT64_MAX;
+  for (int n = 0; n < SWD * SWP; ++n)
+    if (onB[n] >= SWD) ldWp = std::min<int64_t>(ldWp, onB[n]);
+  if (ldWp == INT64_MAX) return false;
+  std::vector<char> seen((size_t)SWD * SWP, 0);
+  for (int n = 0; n < SWD * SWP; ++n) {
+    const int64_t off = onB[n], pp = off / ldWp, rr = off % ldWp;
+    if (off < 0 || pp >= SWP || rr >= SWD || onC[n] != rr || seen[(size_t)(pp * SWD + rr)]) return false;
+    seen[(size_t)(pp * SWD + rr)] = 1;
+  }
+  if (ldA < SWD || ldC < SWD || ldA % 4 || ldC % 4 || ldX % 4 || ldX < SWP || ldWl % 2 || ldWp % 2 || ldWl < SWD) return false;
+  if ((12 * ldWl + 3 * ldWp + SWD) * 4 >= ((int64_t)1 << 31)) return false;   // a lane's offsets into a core: 32 bits
+  sh->ldA = ldA; sh->ldC = ldC; sh->ldWl = ldWl; sh->ldWp = ldWp; sh->ldX = ldX; sh->M = M;
+  return true;
+}
+
+// The longest run of such steps, each taking the result of the one before as its E.
+static bool sweep_match(const Plan& P, Exec::SweepDesc* d) {
+  std::vector<int> best;
+  SweepShape best_first, best_last;
+  std::vector<char> used((size_t)P.n_steps, 0);
+  for (int s0 = 0; s0 < P.n_steps; ++s0) {
+    SweepShape first, cur, last;
+    if (used[s0] || !sweep_step_shape(P, s0, &first)) continue;
+    std::vector<int> run{s0};
+    last = first;
+    for (int s = s0 + 1; s < P.n_steps; ++s) {
+      if (P.steps[s].lhs != P.steps[run.back()].out && P.steps[s].rhs != P.steps[run.back()].out &&
+          P.steps[s].lhs2 != P.steps[run.back()].out)
+        continue;
+      // the consumer of the run's last result: a member if it has the same shape and takes it as its E
+      if (P.steps[s].kernel == CTN_KERNEL_FUSED) continue;   // (the marker of the GEMM the member absorbed)
+      if (P.steps[s].lhs == P.steps[run.back()].out && sweep_step_shape(P, s, &cur) && cur.M == first.M &&
+          cur.ldWl == first.ldWl && cur.ldWp == first.ldWp && cur.ldX == first.ldX && cur.ldA == last.ldC) {
+        run.push_back(s);
+        last = cur;
+        continue;
+      }
+      break;
+    }
+    for (int s : run) used[s] = 1;
+    if (run.size() > best.size()) { best = run; best_first = first; best_last = last; }
+  }
+  if (best.size() < 2) return false;
+  d->on = true; d->steps = best;
+  d->ldIn = best_first.ldA; d->ldOut = best_last.ldC; d->ldWl = best_first.ldWl; d->ldWp = best_first.ldWp; d->ldX = best_first.ldX;
+  d->J = (int)(best_first.M / SWR);
+  return true;
+}
+
 static int exec_launch_steps(Exec* E) {
   const Plan& P = *E->plan;
   const int R = E->R;
@@ -582,6 +670,45 @@ static int exec_launch_steps(Exec* E) {
         continue;
       }
       collect_left = G.len; collect_head = s;   // first time: the steps' arguments are built below, not launched
+    }
+    if (!E->sweep_role.empty() && E->sweep_role[s] && !E->eager_rescale) {
+      if ((int)E->launched_tile.size() != P.n_steps) E->launched_tile.assign(P.n_steps, 0);
+      const bool timed_w = E->timing_runs < E->timing_slots;
+      const size_t ew = timed_w ? ((size_t)E->timing_runs * P.n_steps + s) * 2 : 0;
+      if (timed_w) HIPCHECK(hipEventRecord(E->events[ew], E->stream));
+      if (E->sweep_role[s] == 1) {
+        E->launched_tile[s] = (1 << 16) | 1;        // marker: absorbed into the next launched step
+      } else {                                      // the last member: the whole chain, then its scale bookkeeping
+        const Exec::SweepDesc& sd = E->sweep;
+        const int S = (int)sd.steps.size();
+        const Step& f0 = P.steps[sd.steps.front()];
+        SweepArgs w{};
+        w.ptrs = E->d_ptrs; w.n_tensors = E->n_tensors; w.site_ids = E->d_sweep_ids;
+        w.idIn = f0.lhs; w.idOut = st.out; w.S = S; w.J = sd.J;
+        w.ldIn = sd.ldIn; w.ldOut = sd.ldOut; w.ldWl = sd.ldWl; w.ldWp = sd.ldWp; w.ldX = sd.ldX;
+        w.partIn = nullptr; w.PIn = 0; w.strideIn = 0; w.numelIn = 1.0;
+        if (f0.lhs >= P.n_inputs && P.stabilize && P.steps[P.tensors[f0.lhs].producer].kernel != CTN_KERNEL_FUSED) {
+          const int ps = P.tensors[f0.lhs].producer;
+          w.partIn = E->d_partials + (size_t)E->step_off[ps] * R;
+          w.PIn = w.strideIn = E->step_partials[ps];
+          w.numelIn = (double)P.tensors[f0.lhs].numel;
+        }
+        w.min_norm = P.min_norm;
+        w.rec_a = E->d_sweep_a; w.rec_s = E->d_sweep_s;
+        E->launched_tile[s] = (SWR << 16) | (SWD * SWP);   // 16 rows x all 1024 columns per workgroup, every site
+        hipLaunchKernelGGL(k_sweep_f32, dim3((unsigned)sd.J, (unsigned)R), dim3(512), 0, E->stream, w);
+        const double numel = (double)P.tensors[st.out].numel;
+        hipLaunchKernelGGL(k_sweep_z, dim3((unsigned)S, (unsigned)R), dim3(256), 0, E->stream, (const double*)E->d_sweep_a,
+                           (const float*)E->d_sweep_s, S, sd.J, numel, E->d_sweep_z);
+        SweepFinish f{};
+        f.ptrs = E->d_ptrs; f.n_tensors = E->n_tensors; f.idOut = st.out; f.S = S; f.J = sd.J; f.R = R;
+        f.ldOut = sd.ldOut; f.Z = E->d_sweep_z; f.rec_s = E->d_sweep_s; f.part_off = E->d_sweep_off;
+        f.part_slots = E->d_sweep_slots; f.partials = E->d_partials; f.numel = numel;
+        f.min_norm = P.stabilize ? P.min_norm : INFINITY;
+        hipLaunchKernelGGL(k_sweep_finish, dim3((unsigned)sd.J, (unsigned)R), dim3(256), 0, E->stream, f);
+      }
+      if (timed_w) HIPCHECK(hipEventRecord(E->events[ew + 1], E->stream));
+      continue;
     }
     if (!E->zip_skip.empty() && E->zip_skip[s]) {   // first step of a zipper pair: runs inside the next step's launch
       if ((int)E->launched_tile.size() != P.n_steps) E->launched_tile.assign(P.n_steps, 0);
@@ -1330,6 +1457,33 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
       E.zip.clear(); E.zip_skip.clear();
     }
   }
+  // a sweep: at least half a chip of row blocks, or CTN_SWEEP=1
+  if (!P.chain && E.sw.sweep != 0 && P.stabilize) {
+    Exec::SweepDesc sd;
+    if (sweep_match(P, &sd) && (E.sw.sweep == 1 || (sd.steps.size() >= 4 && (int64_t)sd.J * replicas * 2 >= E.n_cu))) {
+      E.sweep = sd;
+      const int S = (int)sd.steps.size();
+      E.sweep_role.assign(P.n_steps, 0);
+      std::vector<int32_t> ids((size_t)S * 2), slots((size_t)S);
+      std::vector<int64_t> offs((size_t)S);
+      for (int i = 0; i < S; ++i) {
+        const int s = sd.steps[i];
+        E.sweep_role[s] = i + 1 == S ? 2 : 1;
+        ids[2 * i] = P.steps[s].rhs; ids[2 * i + 1] = P.steps[s].lhs2;
+        offs[i] = E.step_off[s]; slots[i] = E.step_partials[s];
+      }
+      HIPCHECK_X(hipMalloc((void**)&E.d_sweep_ids, ids.size() * 4));
+      HIPCHECK_X(hipMemcpy(E.d_sweep_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+      HIPCHECK_X(hipMalloc((void**)&E.d_sweep_off, offs.size() * 8));
+      HIPCHECK_X(hipMemcpy(E.d_sweep_off, offs.data(), offs.size() * 8, hipMemcpyHostToDevice));
+      HIPCHECK_X(hipMalloc((void**)&E.d_sweep_slots, slots.size() * 4));
+      HIPCHECK_X(hipMemcpy(E.d_sweep_slots, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+      const size_t nrec = (size_t)replicas * S * sd.J;
+      HIPCHECK_X(hipMalloc((void**)&E.d_sweep_a, nrec * 8));
+      HIPCHECK_X(hipMalloc((void**)&E.d_sweep_s, nrec * 4));
+      HIPCHECK_X(hipMalloc((void**)&E.d_sweep_z, (size_t)replicas * S * 8));
+    }
+  }
   // leaf groups: runs of consecutive plain streaming steps on network inputs, same kernel variant (see Exec::LeafGroup)
   if (!P.chain && E.sw.group) {
     E.groups.assign(P.n_steps, Exec::LeafGroup());
@@ -1477,6 +1631,10 @@ static bool exec_scales_suspect(const Exec* E, const double* resc = nullptr, int
       };
       if (st.kernel == CTN_KERNEL_FUSED) continue;
       if (!E->zip_skip.empty() && E->zip_skip[s]) continue;          // runs inside the next step's launch
+      if (!E->sweep_role.empty() && E->sweep_role[s] && !E->eager_rescale) {   // a sweep keeps its products in range by itself
+        if (!std::isfinite(rs[s])) return true;
+        continue;
+      }
       double sab = scale_of(st.lhs) * (st.rhs >= 0 ? scale_of(st.rhs) : 1.0) * (st.lhs2 >= 0 ? scale_of(st.lhs2) : 1.0);
       if (!E->zip.empty() && E->zip[s].on)                           // the fused pair accumulates on E, X and Y as stored
         sab = scale_of(P.steps[s - 1].lhs) * scale_of(P.steps[s - 1].rhs) * scale_of(st.rhs);

@@ -1,0 +1,310 @@
+// kernels_sweep.h - an MPS applied to a batch of inputs: every site of the chain inside ONE launch, a block of 16 inputs
+// per workgroup.  Part of the gfx950 contraction engine (see engine.hip for the overview).
+#pragma once
+#include "kernels_mfma_g.h"
+
+namespace ctn {
+
+// ---------------------------------------------------------------------------
+// K-sweep-f32.  BASELINE configs[3b] (reference README Fig. 1d: an MPS classifier on a batch hyperedge; the reference
+// walks it as 2 pairwise steps per site, einsum.py:341-391): per site
+//
+//     C[b, (p, r)] = sum_l E[b, l] W_s[l, p, r]        E'[b, r] = sum_p x_s[b, p] C[b, (p, r)]
+//
+// (one epilogue-summed GEMM step of the plan, 4096 x 1024 x 256 for 4096 inputs at bond 256).  One launch per site is
+// ONE round of 256 workgroups that start and end together: a quarter of its time is prologue, hand-over and epilogue
+// with nothing to cover them, and the site launches depend on each other (LAB_NOTES R3.4).  But the rows b never meet:
+// a block of rows can walk the WHOLE chain on its own.  Here a workgroup owns 16 inputs - 4096 inputs = 256
+// workgroups, one per CU - and keeps their state E (16 x 256) in LDS from the first site to the last; the cores W_s
+// (1 MiB each, the same for every workgroup: L2 hits) stream straight from global memory into MFMA operand registers,
+// no LDS, no barrier inside a site.
+//
+// 8 waves; wave w owns the 32 values r = 32 w .. 32 w + 31 for all p.  v_mfma_f32_16x16x4_f32, D[i][j = b]:
+//   A operand: lane (i = lane & 15, kg = lane >> 4) holds W_s[l][p][32 w + 2 i + c] for c = 0, 1 - one 8-byte load
+//              feeds the two accumulators (p, c): row i of accumulator c is r = 32 w + 2 i + c;
+//   B operand: lane (j = b, kg) holds E[b][l];
+//   k-step t = 0..3 of a group G of 16 values of l pairs lane group kg with l = 16 G + 4 kg + t, so that a lane's four
+//   B operands of a group are ONE 16-byte LDS read (any pairing is fine as long as both operands follow it);
+//   D: lane (b, g = lane >> 4) holds rows i = 4 g + e in register e: after the sum over p a lane has
+//   E'[b][32 w + 8 g + 0..7] - eight consecutive r, written back to the LDS image as two 16-byte stores.
+// The cores are requested 8 k-steps (one loop body) ahead into a register queue that runs on across site
+// boundaries; the only barrier is the one per site between writing E' and reading it.
+//
+// Stabilisation.  The reference rescales by the mean |.| of the WHOLE tensor after every step (einsum.py:97-106),
+// which no workgroup knows.  A workgroup rescales its own 16 rows by THEIR mean instead (any bounded scale keeps
+// the products in range) and records, per site, the abs-sum a[s][j] of its un-rescaled result and the scale
+// s[s][j] it applied.  With g[j][s] = sum_{i <= s} log s[i][j], the whole tensor's mean after site s is
+// exp(Z_s), Z_s = log((1 / numel) sum_j a[s][j] exp(g[j][s - 1])) (k_sweep_z, a log-sum-exp per site), and the
+// reference's rescale factors follow from the Z_s by its own recurrence (k_sweep_finish: rescale_s = exp(Z_s) / R_{s-1}
+// when its norm exceeds min_norm, R_s = exp(Z_s) then, else R_s = R_{s-1}); k_sweep_finish writes them where the
+// per-step launches would have left their abs-sums, and brings the last site's rows - stored by the sweep with each
+// block's own scale - to the one scale the reference's stored tensor has.  Same numbers as the per-site launches up
+// to rounding; three launches instead of one per site.
+//
+// Conditions (engine.hip, sweep_match): fp32, |l| = |r| = 256, |p| = 4, rows a multiple of 16, W_s and x_s network
+// inputs with r and p unit-stride, E row-major.
+// ---------------------------------------------------------------------------
+struct SweepArgs {
+  void* const* ptrs;         // [R][n_tensors]
+  int32_t n_tensors;
+  const int32_t* site_ids;   // [S][2]: tensor ids of (W_s, x_s)
+  int32_t idIn, idOut;       // the chain's input E [b][l] and its output E' [b][r]
+  int32_t S, J;              // sites, row blocks (rows / 16)
+  int64_t ldIn, ldOut;       // row strides of input and output (elements)
+  int64_t ldWl, ldWp;        // W_s[l][p][r]: strides of l and p (r unit-stride)
+  int64_t ldX;               // x_s[b][p]: row stride (p unit-stride)
+  const double* partIn;      // the input's producer partials (nullptr: a network input)
+  int32_t PIn, strideIn;
+  double numelIn, min_norm;
+  double* rec_a;             // [R][S][J] abs-sum of a block's un-rescaled result
+  float* rec_s;              // [R][S][J] the scale the block then applied (1 after the last site)
+};
+
+constexpr int SWD = 256, SWP = 4, SWR = 16, SWLD = SWD + 4;   // (row stride 260: the 16-byte reads of 16 rows spread over the banks)
+constexpr int SWQ = 8;                                        // k-steps of W in flight per wave (one loop body)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) char* sw_gptr;   // global memory, said so: plain global_load / store
+typedef __attribute__((address_space(1))) float* sw_gout;
+typedef float sw_f2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
+  __shared__ __attribute__((aligned(16))) float img[2][SWR * SWLD];
+  __shared__ double red[2][8];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kg = lane >> 4;
+  const int j = blockIdx.x, r = blockIdx.y;
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const size_t rec0 = (size_t)r * a.S * a.J + j;
+
+  // the chain's input, normalised by its producer's mean (the lazy rescale: reference einsum.py:387 on the step before)
+  {
+    double pv = 0.0;
+    if (a.partIn) {
+      const double* __restrict__ pr = a.partIn + (size_t)r * a.strideIn;
+      pv = pr[min(lane, a.PIn - 1)];
+      if (a.PIn > 64)
+        for (int i = lane + 64; i < a.PIn; i += 64) pv += pr[i];
+      pv = lane < a.PIn ? pv : 0.0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) pv += __shfl_xor(pv, o, 64);
+    }
+    const float nI = (float)pv;
+    const float inv = (a.partIn && nI > (float)a.min_norm) ? 1.0f / (nI / (float)a.numelIn) : 1.0f;
+    const float* __restrict__ Ein = (const float*)tp[a.idIn] + (int64_t)(SWR * j) * a.ldIn;
+    const int row = tid >> 5, col = (tid & 31) * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(Ein + (int64_t)row * a.ldIn + col);
+    const float4 v1 = *reinterpret_cast<const float4*>(Ein + (int64_t)row * a.ldIn + col + 4);
+    float* d = &img[0][row * SWLD + col];
+    *reinterpret_cast<float4*>(d) = make_float4(v0.x * inv, v0.y * inv, v0.z * inv, v0.w * inv);
+    *reinterpret_cast<float4*>(d + 4) = make_float4(v1.x * inv, v1.y * inv, v1.z * inv, v1.w * inv);
+  }
+
+  // a lane's own offsets into a core (bytes): row 4 kg of a group, its two columns r of every p
+  uint32_t voff[SWP];
+#pragma unroll
+  for (int p = 0; p < SWP; ++p)
+    voff[p] = (uint32_t)(((int64_t)(4 * kg) * a.ldWl + (int64_t)p * a.ldWp + 32 * w + 2 * i16) * 4);
+  const int64_t stepW = a.ldWl * 4, jumpW = 13 * a.ldWl * 4;   // next k-step of a group / first one of the next group
+
+  sw_gptr Wcur = (sw_gptr)tp[a.site_ids[0]];
+  sw_gptr Xcur = (sw_gptr)tp[a.site_ids[1]];
+  sw_f2 wq[SWQ][SWP];
+  sw_gptr wpf = Wcur;                         // the next k-step to request (wave-uniform)
+  auto wrequest = [&](sw_f2 (&dst)[SWP], int t) {
+#pragma unroll
+    for (int p = 0; p < SWP; ++p) dst[p] = *reinterpret_cast<const __attribute__((address_space(1))) sw_f2*>(wpf + voff[p]);
+    wpf += t == 3 ? jumpW : stepW;
+  };
+#pragma unroll
+  for (int u = 0; u < SWQ; ++u) wrequest(wq[u], u & 3);
+
+  f32x4 acc[SWP][2];
+#pragma unroll
+  for (int p = 0; p < SWP; ++p)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[p][c][e] = 0.f;
+
+  __syncthreads();                            // the input image is in place
+  float inv_s = 1.0f;
+  int cur = 0;
+  sw_gptr Wnext = Wcur, Xnext = Xcur;
+  for (int s = 0; s < a.S; ++s) {
+    const bool last = s + 1 == a.S;
+    // next site's tensors (the last site re-requests its own first k-steps: in bounds, never used)
+    const int sn = last ? s : s + 1;
+    Wnext = (sw_gptr)tp[a.site_ids[2 * sn]];
+    Xnext = (sw_gptr)tp[a.site_ids[2 * sn + 1]];
+    const f32x4 xr = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(Xcur + (int64_t)(SWR * j + i16) * a.ldX * 4);
+    const float* erow = &img[cur][i16 * SWLD + 4 * kg];
+    float4 ef = *reinterpret_cast<const float4*>(erow);
+#pragma unroll 1
+    for (int it = 0; it < SWD / (4 * SWQ); ++it) {     // 8 bodies of 8 k-steps = 2 groups of 16 values of l each
+      if (it == SWD / (4 * SWQ) - 1) wpf = Wnext;      // this body's requests are the next site's first k-steps
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int gn = min(2 * it + half + 1, SWD / 16 - 1);               // the next group's B operands, a group ahead
+        const float4 en = *reinterpret_cast<const float4*>(erow + 16 * gn);  // (after the last group: read again, unused)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int u = 4 * half + t;
+          const float ev = t == 0 ? ef.x : t == 1 ? ef.y : t == 2 ? ef.z : ef.w;
+#pragma unroll
+          for (int p = 0; p < SWP; ++p) {
+            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[u][p].x, ev, acc[p][0], 0, 0, 0);
+            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[u][p].y, ev, acc[p][1], 0, 0, 0);
+          }
+          wrequest(wq[u], t);
+          if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the next group's B operands first
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * SWP, 0);   // this k-step's MFMAs, then its queue slot's requests
+          __builtin_amdgcn_sched_group_barrier(0x020, SWP, 0);
+        }
+        ef = en;
+      }
+    }
+    // ---- the site's epilogue: E'[b][r] = sum_p x[b][p] C[b][(p, r)]; a lane has r = 32 w + 8 kg + 2 e + c ----------
+    // (the state in LDS is the un-rescaled one: its scale goes into the weights - four multiplications per site)
+    const float xs[4] = {xr.x * inv_s, xr.y * inv_s, xr.z * inv_s, xr.w * inv_s};
+    float o[8];
+    float asum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float v = xs[0] * acc[0][c][e];
+        v = fmaf(xs[1], acc[1][c][e], v);
+        v = fmaf(xs[2], acc[2][c][e], v);
+        v = fmaf(xs[3], acc[3][c][e], v);
+        o[2 * e + c] = v;
+        asum += fabsf(v);
+      }
+#pragma unroll
+    for (int p = 0; p < SWP; ++p)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[p][c][e] = 0.f;
+    const int nxt = cur ^ 1;
+    // (the last site's rows leave with this block's own scale; k_sweep_finish brings them to the common one)
+    if (last) {
+      sw_gout dst = (sw_gout)tp[a.idOut] + (int64_t)(SWR * j + i16) * a.ldOut + 32 * w + 8 * kg;
+      *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    } else {
+      float* dst = &img[nxt][i16 * SWLD + 32 * w + 8 * kg];
+      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    double part = (double)asum;
+#pragma unroll
+    for (int of = 32; of > 0; of >>= 1) part += __shfl_xor(part, of, 64);
+    if (lane == 0) red[nxt][w] = part;
+    // one barrier per site; only the LDS traffic is waited for - the cores requested ahead stay in flight
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += red[nxt][i];
+    const float sc = (!last && tot > 1e-30) ? (float)(tot / (double)(SWR * SWD)) : 1.0f;
+    inv_s = 1.0f / sc;
+    if (tid == 0) {
+      a.rec_a[rec0 + (size_t)s * a.J] = tot;
+      a.rec_s[rec0 + (size_t)s * a.J] = sc;
+    }
+    cur = nxt;
+    Wcur = Wnext;
+    Xcur = Xnext;
+  }
+}
+
+// Z_s = log of the whole tensor's mean |.| after site s of a sweep, from the blocks' records (see k_sweep_f32).
+// grid (S, R), 256 threads; fixed-order sums.
+__global__ __launch_bounds__(256) void k_sweep_z(const double* __restrict__ rec_a, const float* __restrict__ rec_s, int S, int J,
+                                                 double numel, double* __restrict__ Z) {
+  __shared__ double red[4];
+  const int s = blockIdx.x, r = blockIdx.y;
+  const double* ra = rec_a + (size_t)r * S * J;
+  const float* rs = rec_s + (size_t)r * S * J;
+  // a block's term: log a[s][j] + sum_{i < s} log s[i][j]
+  double mx = -INFINITY;
+  for (int j = threadIdx.x; j < J; j += 256) {
+    double g = 0.0;
+    for (int i = 0; i < s; ++i) g += log((double)rs[(size_t)i * J + j]);
+    const double av = ra[(size_t)s * J + j];
+    const double t = av > 0.0 ? log(av) + g : -INFINITY;
+    mx = fmax(mx, t);
+  }
+#pragma unroll
+  for (int of = 32; of > 0; of >>= 1) mx = fmax(mx, __shfl_xor(mx, of, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  __syncthreads();
+  if (mx == -INFINITY) {                      // an all-zero tensor
+    if (threadIdx.x == 0) Z[(size_t)r * S + s] = -INFINITY;
+    return;
+  }
+  double sum = 0.0;
+  for (int j = threadIdx.x; j < J; j += 256) {
+    double g = 0.0;
+    for (int i = 0; i < s; ++i) g += log((double)rs[(size_t)i * J + j]);
+    const double av = ra[(size_t)s * J + j];
+    if (av > 0.0) sum += exp(log(av) + g - mx);
+  }
+  const double tot = block_sum(sum, red);
+  if (threadIdx.x == 0) Z[(size_t)r * S + s] = mx + log(tot) - log(numel);
+}
+
+// The reference's rescale factors of a sweep's steps from the Z_s, and the last site's rows at the common scale.
+// grid (J, R), 256 threads.  part_off[s] = first slot of chain step s in the partials buffer (per replica: slots[s]).
+struct SweepFinish {
+  void* const* ptrs;
+  int32_t n_tensors, idOut, S, J, R;
+  int64_t ldOut;
+  const double* Z;           // [R][S]
+  const float* rec_s;        // [R][S][J]
+  const int64_t* part_off;   // [S]: d_partials offset (in doubles) of the step's region for replica 0 = off[s] * R
+  const int32_t* part_slots; // [S]
+  double* partials;
+  double numel, min_norm;
+};
+
+__global__ __launch_bounds__(256) void k_sweep_finish(SweepFinish f) {
+  const int j = blockIdx.x, r = blockIdx.y;
+  const double* Z = f.Z + (size_t)r * f.S;
+  // the reference's recurrence (einsum.py:97-106 over the chain's steps): norm_s = numel exp(Z_s) / R_{s-1};
+  // rescaled iff norm_s > min_norm, then R_s = exp(Z_s)
+  double logR = 0.0, logR_before_last = 0.0;
+  for (int s = 0; s < f.S; ++s) {
+    const double norm = Z[s] == -INFINITY ? 0.0 : f.numel * exp(Z[s] - logR);
+    if (s + 1 == f.S) logR_before_last = logR;
+    if (j == 0) {                             // what the step's own launch would have left: its abs-sum (slot 0)
+      double* dst = f.partials + (size_t)f.part_off[s] * f.R + (size_t)r * f.part_slots[s];
+      for (int i = threadIdx.x; i < f.part_slots[s]; i += 256) dst[i] = i == 0 ? norm : 0.0;
+    }
+    if (norm > f.min_norm) logR = Z[s];
+  }
+  // this block's rows of the last site: V = W exp(g[j][S - 2]); stored tensor of the reference = V / R_{S-2}
+  double g = 0.0;
+  const float* rs = f.rec_s + (size_t)r * f.S * f.J + j;
+  for (int i = 0; i + 1 < f.S; ++i) g += log((double)rs[(size_t)i * f.J]);
+  const float fac = (float)exp(g - logR_before_last);
+  float* out = (float*)f.ptrs[(size_t)r * f.n_tensors + f.idOut] + (int64_t)(SWR * j) * f.ldOut;
+  for (int i = threadIdx.x; i < SWR * SWD / 4; i += 256) {
+    const int row = i / (SWD / 4), c4 = i - row * (SWD / 4);
+    float4* p = reinterpret_cast<float4*>(out + (int64_t)row * f.ldOut) + c4;
+    float4 v = *p;
+    v.x *= fac; v.y *= fac; v.z *= fac; v.w *= fac;
+    *p = v;
+  }
+}
+
+}  // namespace ctn

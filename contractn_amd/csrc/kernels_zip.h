@@ -1,6 +1,7 @@
 // kernels_zip.h - two consecutive GEMM steps of a "zipper" as ONE launch: the intermediate never leaves the registers.
 // Part of the gfx950 contraction engine (see engine.hip for the overview).
 #pragma once
+#include <type_traits>
 #include "kernels_mfma_g.h"
 
 namespace ctn {
@@ -55,7 +56,7 @@ struct ZipArgs {
 
 constexpr int ZM = 256, ZU = 128, ZK = 16, ZSTG = 8192;   // stage: 8192 floats = 32 KiB
 constexpr bool ZPF = (CTN_EXP & 1) != 0;      // experiment: the first fragments of a tile are read at the end of the tile before
-constexpr int ZST = (CTN_EXP & 2) ? 4 : 3;    // experiment: ring depth
+constexpr int ZST = 3;                         // ring depth (4 measured: the requests are never waited for, nothing to gain)
 
 __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[ZST * ZSTG + 16];
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
 
   for (int q = 0; q < a.Q; ++q) {
     // ---- phase 1: Tq[m1 half kh, u-block ub] = sum_k1 E[k1][m1] Xq[k1][u] ------------------------------------
-    for (int s = 0; s < T1; ++s) {
+    auto tile1 = [&](auto last) {                // one phase-1 tile; last: the next tile is a phase-2 tile
       const float* cA = smem + st_cur * ZSTG + h * ZM + kh * (ZM / 2) + l31;       // E image [k1][256]
       const float* cB = smem + st_cur * ZSTG + 4096 + h * ZU + ub * 32 + l31;      // Xq image [k1][128]
       if (!ZPF) {
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
           fb[nx] = cB[2 * (kk + 1) * ZU];
         } else if (ZPF) {                        // the next tile (landed: this tile's barrier is behind us): its first fragments
           const float* nS = smem + st_nxt * ZSTG;
-          if (s + 1 < T1) {
+          if (!decltype(last)::value) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[0][i] = nS[h * ZM + kh * (ZM / 2) + l31 + 32 * i];
             fb[0] = nS[4096 + h * ZU + ub * 32 + l31];
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
         for (int i = 0; i < 4; ++i)
           acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c], acc1[i], 0, 0, 0);   // D1[m1][u]
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (ZPF && decltype(last)::value) ? 8 : 5, 0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
@@ -233,6 +234,12 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
         if (kk == bar_at) middle();
       }
       advance();
+    };
+    if (ZPF) {
+      for (int s = 0; s + 1 < T1; ++s) tile1(std::false_type{});
+      tile1(std::true_type{});
+    } else {
+      for (int s = 0; s < T1; ++s) tile1(std::false_type{});
     }
     // ---- phase 2: E'[u-block ub, :] += sum over this half's m1 of Tq[m1][u] Yq[m1][n2] -------------------------
 #pragma unroll
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
           if (ms + 1 < T2) {
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) fy[0][nb] = nS[kh * 4096 + (4 * h) * ZM + l31 + 32 * nb];
-          } else if (t + 1 < TT) {
+          } else {                               // (after the last tile of all: stale floats, never used)
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[0][i] = nS[h * ZM + kh * (ZM / 2) + l31 + 32 * i];
             fb[0] = nS[4096 + h * ZU + ub * 32 + l31];

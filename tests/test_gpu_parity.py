@@ -1175,3 +1175,62 @@ def test_zipper_pairs_in_one_launch_match_the_two_step_path(sites, phys, replica
             assert float(res[mode][0][r]) == float(rt) and abs(float(res[mode][1][r]) - float(rc)) <= 1e-4, (mode, r)
     monkeypatch.delenv("CTN_ZIP")
     E.clear_caches()
+
+
+# ---- a batched MPS as ONE launch (k_sweep_f32): 16 inputs per workgroup walk every site of the chain --------------------
+@pytest.mark.parametrize("sites,batch,replicas,spread", [(6, 64, 1, 1.0), (9, 160, 2, 1.0), (7, 80, 1, 1e6)])
+def test_sweep_of_a_batched_mps_matches_the_per_site_launches(sites, batch, replicas, spread, monkeypatch):
+    """The reference's ML workload (README Fig. 1d; BASELINE config 3b) at bond 256, physical dimension 4: with
+    CTN_SWEEP=1 the interior sites - one epilogue-summed GEMM step each - run as ONE k_sweep_f32 launch in which
+    every block of 16 inputs rescales by its OWN mean; k_sweep_z / k_sweep_finish reconstruct the reference's
+    per-step rescale factors (mean over ALL inputs, einsum.py:97-106).  Against the per-site launches (CTN_SWEEP=0):
+    result, log-scale and EVERY step's rescale factor; against the oracle; replicas; blocks of very different
+    magnitude (`spread`: the inputs of the second half of the batch are that much larger)."""
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from oracle import cpu_ref
+    from tests import networks as nets
+
+    bond, phys = 256, 4
+    tn, inputs = nets.batched_mps(TN, sites, bond, phys, batch, dtype=np.float32, seed=4)
+    path = ssa_to_linear(nets.batched_mps_path(sites), 2 * sites)
+    ops0 = [np.asarray(o) for o in E.make_arg_packer(tn)(tn.params, inputs)]
+    shapes = [o.shape for o in ops0]
+    rng = np.random.default_rng(7)
+    sets = []
+    for r in range(replicas):
+        ops = [(rng.standard_normal(sh) * (0.25 if len(sh) == 2 and sh[0] == batch else 1.0 / 16.0)).astype(np.float32) for sh in shapes]
+        if spread != 1.0:
+            for o in ops:
+                if o.shape == (batch, phys):
+                    o[batch // 2:] *= np.float32(spread ** (1.0 / sites))
+        sets.append(ops)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CTN_SWEEP", mode)
+        E.clear_caches()
+        bc = E.BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=replicas)
+        t, c = bc.run_host(sets)
+        t2, c2 = bc.run_host(sets)                     # graph capture / replay: the same bits
+        assert np.array_equal(t, t2) and np.array_equal(c, c2)
+        res[mode] = (t, c, bc.executor.step_tiles(), bc.executor.fetch()[1])
+        bc.executor.close()
+    tiles = res["1"][2]
+    whole = [s for s, tl in enumerate(tiles) if tl == (16, 1024)]
+    assert len(whole) == 1 and sum(tl == (1, 1) for tl in tiles) >= sites - 3, tiles
+    assert not any(tl == (16, 1024) for tl in res["0"][2])
+    for r in range(replicas):
+        r0, r1 = np.asarray(res["0"][3][r]), np.asarray(res["1"][3][r])
+        assert np.array_equal(r0 == 0.0, r1 == 0.0)                               # the same steps are rescaled
+        nz = r0 != 0.0
+        assert np.max(np.abs(r1[nz] / r0[nz] - 1.0)) <= 2e-5, (r0, r1)            # ... by the same factors
+        assert abs(float(res["0"][1][r]) - float(res["1"][1][r])) <= 1e-4
+        a = res["0"][0][r].astype(np.float64) * np.exp(float(res["0"][1][r]))
+        b = res["1"][0][r].astype(np.float64) * np.exp(float(res["1"][1][r]))
+        assert np.max(np.abs(a - b)) <= 2e-5 * np.max(np.abs(a))
+        rt, rc = cpu_ref.contract(tn.einsum_str, *sets[r], path=path, split_format=True)
+        ref = np.asarray(rt, dtype=np.float64) * np.exp(float(rc))
+        assert np.max(np.abs(b - ref)) <= 1e-4 * np.max(np.abs(ref))
+        assert abs(float(np.mean(np.abs(res["1"][0][r]))) - 1.0) < 1e-5 and abs(float(res["1"][1][r]) - float(rc)) <= 1e-4
+    monkeypatch.delenv("CTN_SWEEP")
+    E.clear_caches()
