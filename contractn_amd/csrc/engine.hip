@@ -597,8 +597,8 @@ static bool sweep_step_shape(const Plan& P, int s, SweepShape* sh) {
     if (off < 0 || pp >= SWP || rr >= SWD || onC[n] != rr || seen[(size_t)(pp * SWD + rr)]) return false;
     seen[(size_t)(pp * SWD + rr)] = 1;
   }
-  if (ldA < SWD || ldC < SWD || ldA % 4 || ldC % 4 || ldX % 4 || ldX < SWP || ldWl % 2 || ldWp % 2 || ldWl < SWD) return false;
-  if ((12 * ldWl + 3 * ldWp + SWD) * 4 >= ((int64_t)1 << 31)) return false;   // a lane's offsets into a core: 32 bits
+  if (ldA < SWD || ldC < SWD || ldA % 4 || ldC % 4 || ldX % 4 || ldX < SWP || ldWl % 4 || ldWp % 4 || ldWl < SWD) return false;
+  if (((SWD / 2 + 12) * ldWl + 3 * ldWp + SWD) * 4 >= ((int64_t)1 << 31)) return false;   // a lane's offsets into a core: 32 bits
   sh->ldA = ldA; sh->ldC = ldC; sh->ldWl = ldWl; sh->ldWp = ldWp; sh->ldX = ldX; sh->M = M;
   return true;
 }
@@ -694,8 +694,18 @@ static int exec_launch_steps(Exec* E) {
           w.numelIn = (double)P.tensors[f0.lhs].numel;
         }
         w.min_norm = P.min_norm;
-        w.rec_a = E->d_sweep_a; w.rec_s = E->d_sweep_s;
+        w.rec_a = E->d_sweep_a; w.rec_s = E->d_sweep_s; w.dbg = nullptr;
         E->launched_tile[s] = (SWR << 16) | (SWD * SWP);   // 16 rows x all 1024 columns per workgroup, every site
+        if (E->sw.stamps && (E->sw.stamp_step < 0 || E->sw.stamp_step == s)) {
+          const size_t need = (size_t)sd.J * R;
+          if (E->dbg_tiles < need) {
+            if (E->d_dbg) (void)hipFree(E->d_dbg);
+            HIPCHECK(hipMalloc((void**)&E->d_dbg, need * 64));
+            E->dbg_tiles = need;
+          }
+          w.dbg = E->d_dbg;
+          HIPCHECK(hipMemsetAsync(E->d_dbg, 0, E->dbg_tiles * 64, E->stream));
+        }
         hipLaunchKernelGGL(k_sweep_f32, dim3((unsigned)sd.J, (unsigned)R), dim3(512), 0, E->stream, w);
         const double numel = (double)P.tensors[st.out].numel;
         hipLaunchKernelGGL(k_sweep_z, dim3((unsigned)S, (unsigned)R), dim3(256), 0, E->stream, (const double*)E->d_sweep_a,

@@ -19,16 +19,17 @@ namespace ctn {
 // (1 MiB each, the same for every workgroup: L2 hits) stream straight from global memory into MFMA operand registers,
 // no LDS, no barrier inside a site.
 //
-// 8 waves; wave w owns the 32 values r = 32 w .. 32 w + 31 for all p.  v_mfma_f32_16x16x4_f32, D[i][j = b]:
-//   A operand: lane (i = lane & 15, kg = lane >> 4) holds W_s[l][p][32 w + 2 i + c] for c = 0, 1 - one 8-byte load
-//              feeds the two accumulators (p, c): row i of accumulator c is r = 32 w + 2 i + c;
+// 8 waves = 4 ranges of 64 values of r x the 2 halves of l.  v_mfma_f32_16x16x4_f32, D[i][j = b]:
+//   A operand: lane (i = lane & 15, kg = lane >> 4) holds W_s[l][p][64 w4 + 4 i + c] for c = 0..3 - one 16-byte load
+//              (every CU reads every core from its XCD's L2: 8-byte requests reach 0.6 of the rate of 16-byte ones)
+//              feeds the four accumulators (p, c): row i of accumulator c is r = 64 w4 + 4 i + c;
 //   B operand: lane (j = b, kg) holds E[b][l];
 //   k-step t = 0..3 of a group G of 16 values of l pairs lane group kg with l = 16 G + 4 kg + t, so that a lane's four
 //   B operands of a group are ONE 16-byte LDS read (any pairing is fine as long as both operands follow it);
-//   D: lane (b, g = lane >> 4) holds rows i = 4 g + e in register e: after the sum over p a lane has
-//   E'[b][32 w + 8 g + 0..7] - eight consecutive r, written back to the LDS image as two 16-byte stores.
-// The cores are requested 8 k-steps (one loop body) ahead into a register queue that runs on across site
-// boundaries; the only barrier is the one per site between writing E' and reading it.
+//   D: lane (b, g = lane >> 4) holds rows i = 4 g + e in register e: after the sum over p a lane has its half's
+//   share of E'[b][64 w4 + 16 g + 0..15]; the two halves of l meet through LDS, each finishing eight of the sixteen.
+// The cores are requested 4 k-steps (one loop body) ahead into a register queue that runs on across site
+// boundaries; two barriers per site (E' complete; its abs-sum known), nothing but LDS traffic is waited for.
 //
 // Stabilisation.  The reference rescales by the mean |.| of the WHOLE tensor after every step (einsum.py:97-106),
 // which no workgroup knows.  A workgroup rescales its own 16 rows by THEIR mean instead (any bounded scale keeps
@@ -58,26 +59,29 @@ struct SweepArgs {
   double numelIn, min_norm;
   double* rec_a;             // [R][S][J] abs-sum of a block's un-rescaled result
   float* rec_s;              // [R][S][J] the scale the block then applied (1 after the last site)
+  unsigned long long* dbg;   // CTN_STAMPS builds only
 };
 
 constexpr int SWD = 256, SWP = 4, SWR = 16, SWLD = SWD + 4;   // (row stride 260: the 16-byte reads of 16 rows spread over the banks)
-constexpr int SWQ = 8;                                        // k-steps of W in flight per wave (one loop body)
+constexpr int SWQ = 4;      // k-steps of W in flight per wave (one loop body; 8 measured: the same - the CU's own load path is the limit)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) char* sw_gptr;   // global memory, said so: plain global_load / store
 typedef __attribute__((address_space(1))) float* sw_gout;
-typedef float sw_f2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
   __shared__ __attribute__((aligned(16))) float img[2][SWR * SWLD];
-  __shared__ double red[2][8];
+  __shared__ __attribute__((aligned(16))) float xch[8 * 2 * 64 * 4];   // the halves' hand-over: 2 x 16 bytes per lane
+  __shared__ double red[8];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w4 = w & 3, kh = w >> 2;
   const int i16 = lane & 15, kg = lane >> 4;
   const int j = blockIdx.x, r = blockIdx.y;
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const size_t rec0 = (size_t)r * a.S * a.J + j;
+  const int srow = tid >> 5, scol = (tid & 31) * 8;   // a thread's share of a 16 x 256 image: 8 consecutive floats
 
   // the chain's input, normalised by its producer's mean (the lazy rescale: reference einsum.py:387 on the step before)
   {
@@ -94,45 +98,53 @@ __global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
     const float nI = (float)pv;
     const float inv = (a.partIn && nI > (float)a.min_norm) ? 1.0f / (nI / (float)a.numelIn) : 1.0f;
     const float* __restrict__ Ein = (const float*)tp[a.idIn] + (int64_t)(SWR * j) * a.ldIn;
-    const int row = tid >> 5, col = (tid & 31) * 8;
-    const float4 v0 = *reinterpret_cast<const float4*>(Ein + (int64_t)row * a.ldIn + col);
-    const float4 v1 = *reinterpret_cast<const float4*>(Ein + (int64_t)row * a.ldIn + col + 4);
-    float* d = &img[0][row * SWLD + col];
+    const float4 v0 = *reinterpret_cast<const float4*>(Ein + (int64_t)srow * a.ldIn + scol);
+    const float4 v1 = *reinterpret_cast<const float4*>(Ein + (int64_t)srow * a.ldIn + scol + 4);
+    float* d = &img[0][srow * SWLD + scol];
     *reinterpret_cast<float4*>(d) = make_float4(v0.x * inv, v0.y * inv, v0.z * inv, v0.w * inv);
     *reinterpret_cast<float4*>(d + 4) = make_float4(v1.x * inv, v1.y * inv, v1.z * inv, v1.w * inv);
   }
 
-  // a lane's own offsets into a core (bytes): row 4 kg of a group, its two columns r of every p
+  // a lane's own offsets into a core (bytes): row 4 kg of a group of its wave's half of l, its four columns r of every p
   uint32_t voff[SWP];
 #pragma unroll
   for (int p = 0; p < SWP; ++p)
-    voff[p] = (uint32_t)(((int64_t)(4 * kg) * a.ldWl + (int64_t)p * a.ldWp + 32 * w + 2 * i16) * 4);
-  const int64_t stepW = a.ldWl * 4, jumpW = 13 * a.ldWl * 4;   // next k-step of a group / first one of the next group
+    voff[p] = (uint32_t)(((int64_t)(SWD / 2 * kh + 4 * kg) * a.ldWl + (int64_t)p * a.ldWp + 64 * w4 + 4 * i16) * 4);
+  const int64_t stepW = a.ldWl * 4;           // next k-step of a group (bytes)
 
   sw_gptr Wcur = (sw_gptr)tp[a.site_ids[0]];
   sw_gptr Xcur = (sw_gptr)tp[a.site_ids[1]];
-  sw_f2 wq[SWQ][SWP];
-  sw_gptr wpf = Wcur;                         // the next k-step to request (wave-uniform)
-  auto wrequest = [&](sw_f2 (&dst)[SWP], int t) {
+  f32x4 wq[SWQ][SWP];
+  // the groups of a site are walked from a block-dependent start (CUs of one XCD then ask its L2 for different lines)
+  const int rot = (j >> 3) & 7;               // (-3 % of the time against every block starting at group 0)
+  sw_gptr wpf = Wcur + (int64_t)(16 * rot) * stepW;   // the group being requested (wave-uniform)
+  auto wrequest = [&](f32x4 (&dst)[SWP], int t) {
 #pragma unroll
-    for (int p = 0; p < SWP; ++p) dst[p] = *reinterpret_cast<const __attribute__((address_space(1))) sw_f2*>(wpf + voff[p]);
-    wpf += t == 3 ? jumpW : stepW;
+    for (int p = 0; p < SWP; ++p) dst[p] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(wpf + (int64_t)t * stepW + voff[p]);
   };
 #pragma unroll
-  for (int u = 0; u < SWQ; ++u) wrequest(wq[u], u & 3);
+  for (int u = 0; u < SWQ; ++u) {
+    if (u == 4) wpf = Wcur + (int64_t)(16 * ((rot + 1) & 7)) * stepW;
+    wrequest(wq[u], u & 3);
+  }
 
-  f32x4 acc[SWP][2];
+  f32x4 acc[SWP][4];
 #pragma unroll
   for (int p = 0; p < SWP; ++p)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[p][c][e] = 0.f;
 
   __syncthreads();                            // the input image is in place
+#ifdef CTN_STAMPS
+  unsigned long long st_loop = 0, st_epi = 0, st0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_begin = st0;
+#endif
   float inv_s = 1.0f;
   int cur = 0;
   sw_gptr Wnext = Wcur, Xnext = Xcur;
+  constexpr int NG = SWD / 2 / 16;            // groups of 16 values of l per wave and site: its half of l
   for (int s = 0; s < a.S; ++s) {
     const bool last = s + 1 == a.S;
     // next site's tensors (the last site re-requests its own first k-steps: in bounds, never used)
@@ -140,79 +152,116 @@ __global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
     Wnext = (sw_gptr)tp[a.site_ids[2 * sn]];
     Xnext = (sw_gptr)tp[a.site_ids[2 * sn + 1]];
     const f32x4 xr = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(Xcur + (int64_t)(SWR * j + i16) * a.ldX * 4);
-    const float* erow = &img[cur][i16 * SWLD + 4 * kg];
-    float4 ef = *reinterpret_cast<const float4*>(erow);
+    const float* erow = &img[cur][i16 * SWLD + SWD / 2 * kh + 4 * kg];
+    float4 ef = *reinterpret_cast<const float4*>(erow + 16 * rot);
+    constexpr int GB = SWQ / 4;                        // groups per loop body = groups requested ahead
 #pragma unroll 1
-    for (int it = 0; it < SWD / (4 * SWQ); ++it) {     // 8 bodies of 8 k-steps = 2 groups of 16 values of l each
-      if (it == SWD / (4 * SWQ) - 1) wpf = Wnext;      // this body's requests are the next site's first k-steps
+    for (int G0 = 0; G0 < NG; G0 += GB) {
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int gn = min(2 * it + half + 1, SWD / 16 - 1);               // the next group's B operands, a group ahead
-        const float4 en = *reinterpret_cast<const float4*>(erow + 16 * gn);  // (after the last group: read again, unused)
+      for (int gb = 0; gb < GB; ++gb) {
+        const int G = G0 + gb;
+        const int gn = (G + 1 + rot) & (NG - 1);       // the next group: its B operands
+        const int gq = (G + GB + rot) & (NG - 1);      // the group GB ahead: its cores' requests (past the last: the next site's)
+        wpf = (G + GB >= NG ? Wnext : Wcur) + (int64_t)(16 * gq) * stepW;
+        const float4 en = *reinterpret_cast<const float4*>(erow + 16 * gn);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int u = 4 * half + t;
           const float ev = t == 0 ? ef.x : t == 1 ? ef.y : t == 2 ? ef.z : ef.w;
 #pragma unroll
-          for (int p = 0; p < SWP; ++p) {
-            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[u][p].x, ev, acc[p][0], 0, 0, 0);
-            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[u][p].y, ev, acc[p][1], 0, 0, 0);
-          }
-          wrequest(wq[u], t);
+          for (int p = 0; p < SWP; ++p)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              // (LAB_NOTES R3.6, cycles per site of the slower wave of a SIMD: these MFMAs alone, on a queue that is
+              // never refilled, 34 k - the ideal is 32.8 k; the stream alone, one FMA here, ~36 k; together 44 k, on 128
+              // CUs as on 256: a CU's own load path, not the L2, sets the pace)
+              acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[4 * gb + t][p][c], ev, acc[p][c], 0, 0, 0);
+            }
+          wrequest(wq[4 * gb + t], t);
           if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the next group's B operands first
-          __builtin_amdgcn_sched_group_barrier(0x008, 2 * SWP, 0);   // this k-step's MFMAs, then its queue slot's requests
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * SWP, 0);         // this k-step's MFMAs, then its queue slot's requests
           __builtin_amdgcn_sched_group_barrier(0x020, SWP, 0);
         }
         ef = en;
       }
     }
-    // ---- the site's epilogue: E'[b][r] = sum_p x[b][p] C[b][(p, r)]; a lane has r = 32 w + 8 kg + 2 e + c ----------
-    // (the state in LDS is the un-rescaled one: its scale goes into the weights - four multiplications per site)
+#ifdef CTN_STAMPS
+    { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); st_loop += t1 - st0; st0 = t1; }
+#endif
+    // ---- the site's epilogue: E'[b][r] = sum_p x[b][p] C[b][(p, r)], this wave's half of the sum over l; a lane has
+    // r = 64 w4 + 16 kg + 4 e + c.  The two halves meet through LDS: each hands the other one two of its four e and
+    // finishes the other two (first half + second half).  The state in LDS is the un-rescaled one: its scale goes into
+    // the weights - four multiplications per site.  (ds_add_f32 into a zeroed image instead: 12 k cycles per site.)
     const float xs[4] = {xr.x * inv_s, xr.y * inv_s, xr.z * inv_s, xr.w * inv_s};
-    float o[8];
-    float asum = 0.f;
+    const int nxt = cur ^ 1;
+    // o[e][c], e = 0..3: this wave keeps e = 2 kh, 2 kh + 1 ("mine") and hands over the other two ("give")
+    float mine[2][4], give[2][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < 4; ++c) {
         float v = xs[0] * acc[0][c][e];
         v = fmaf(xs[1], acc[1][c][e], v);
         v = fmaf(xs[2], acc[2][c][e], v);
         v = fmaf(xs[3], acc[3][c][e], v);
-        o[2 * e + c] = v;
-        asum += fabsf(v);
+        if (e < 2) { mine[e][c] = v; } else { give[e - 2][c] = v; }
       }
+    if (kh) {                                  // (wave-uniform: the second half keeps e = 2, 3)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float tsw = mine[e][c]; mine[e][c] = give[e][c]; give[e][c] = tsw; }
+    }
 #pragma unroll
     for (int p = 0; p < SWP; ++p)
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[p][c][e] = 0.f;
-    const int nxt = cur ^ 1;
-    // (the last site's rows leave with this block's own scale; k_sweep_finish brings them to the common one)
-    if (last) {
-      sw_gout dst = (sw_gout)tp[a.idOut] + (int64_t)(SWR * j + i16) * a.ldOut + 32 * w + 8 * kg;
-      *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
-      *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
-    } else {
-      float* dst = &img[nxt][i16 * SWLD + 32 * w + 8 * kg];
-      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-      *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    {
+      float4* gv = reinterpret_cast<float4*>(xch) + (w * 2) * 64 + lane;
+      gv[0] = make_float4(give[0][0], give[0][1], give[0][2], give[0][3]);
+      gv[64] = make_float4(give[1][0], give[1][1], give[1][2], give[1][3]);
     }
-    double part = (double)asum;
-#pragma unroll
-    for (int of = 32; of > 0; of >>= 1) part += __shfl_xor(part, of, 64);
-    if (lane == 0) red[nxt][w] = part;
-    // one barrier per site; only the LDS traffic is waited for - the cores requested ahead stay in flight
+    // two barriers per site; only the LDS traffic is waited for - the cores requested ahead stay in flight
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    {
+      const float4* take = reinterpret_cast<const float4*>(xch) + ((w ^ 4) * 2) * 64 + lane;
+      const float4 t0 = take[0], t1 = take[64];
+      const float4 m0 = make_float4(mine[0][0], mine[0][1], mine[0][2], mine[0][3]);
+      const float4 m1 = make_float4(mine[1][0], mine[1][1], mine[1][2], mine[1][3]);
+      const float4 f0 = make_float4(m0.x + t0.x, m0.y + t0.y, m0.z + t0.z, m0.w + t0.w);
+      const float4 f1 = make_float4(m1.x + t1.x, m1.y + t1.y, m1.z + t1.z, m1.w + t1.w);
+      const int col = 64 * w4 + 16 * kg + 8 * kh;          // e = 2 kh, 2 kh + 1: eight consecutive r
+      if (last) {     // the last site's rows leave with this block's own scale (k_sweep_finish brings them to the common one)
+        sw_gout og = (sw_gout)tp[a.idOut] + (int64_t)(SWR * j + i16) * a.ldOut + col;
+        *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(og) = f32x4{f0.x, f0.y, f0.z, f0.w};
+        *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(og + 4) = f32x4{f1.x, f1.y, f1.z, f1.w};
+      } else {
+        float* d = &img[nxt][i16 * SWLD + col];
+        *reinterpret_cast<float4*>(d) = f0;
+        *reinterpret_cast<float4*>(d + 4) = f1;
+      }
+      const float asum = ((fabsf(f0.x) + fabsf(f0.y)) + (fabsf(f0.z) + fabsf(f0.w))) +
+                         ((fabsf(f1.x) + fabsf(f1.y)) + (fabsf(f1.z) + fabsf(f1.w)));
+      double part = (double)asum;
+#pragma unroll
+      for (int of = 32; of > 0; of >>= 1) part += __shfl_xor(part, of, 64);
+      if (lane == 0) red[w] = part;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     double tot = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) tot += red[nxt][i];
+    for (int i = 0; i < 8; ++i) tot += red[i];
     const float sc = (!last && tot > 1e-30) ? (float)(tot / (double)(SWR * SWD)) : 1.0f;
     inv_s = 1.0f / sc;
     if (tid == 0) {
@@ -222,7 +271,16 @@ __global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
     cur = nxt;
     Wcur = Wnext;
     Xcur = Xnext;
+#ifdef CTN_STAMPS
+    { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); st_epi += t1 - st0; st0 = t1; }
+#endif
   }
+#ifdef CTN_STAMPS
+  if (a.dbg && (tid == 0 || tid == 448)) {
+    unsigned long long* d = a.dbg + ((size_t)r * a.J + j) * 8 + (tid ? 4 : 0);
+    d[0] = st_begin; d[1] = st0; d[2] = st_loop; d[3] = st_epi;
+  }
+#endif
 }
 
 // Z_s = log of the whole tensor's mean |.| after site s of a sweep, from the blocks' records (see k_sweep_f32).

@@ -1,7 +1,6 @@
 // kernels_zip.h - two consecutive GEMM steps of a "zipper" as ONE launch: the intermediate never leaves the registers.
 // Part of the gfx950 contraction engine (see engine.hip for the overview).
 #pragma once
-#include <type_traits>
 #include "kernels_mfma_g.h"
 
 namespace ctn {
@@ -55,8 +54,7 @@ struct ZipArgs {
 };
 
 constexpr int ZM = 256, ZU = 128, ZK = 16, ZSTG = 8192;   // stage: 8192 floats = 32 KiB
-constexpr bool ZPF = (CTN_EXP & 1) != 0;      // experiment: the first fragments of a tile are read at the end of the tile before
-constexpr int ZST = 3;                         // ring depth (4 measured: the requests are never waited for, nothing to gain)
+constexpr int ZST = 3;     // ring depth (4 measured: the requests are never waited for - 768 cycles per workgroup - nothing to gain)
 
 __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[ZST * ZSTG + 16];
@@ -164,9 +162,8 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
 #ifdef CTN_STAMPS
     const unsigned long long s0 = __builtin_amdgcn_s_memtime();
 #endif
-    // tile t + 1 has landed: this wave's requests, a tile old (ring of 4: two tiles old, tile t + 2's may be in flight)
-    if (ZST == 4 && t + 2 < TT) __builtin_amdgcn_s_waitcnt(0x0F73);
-    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    // vmcnt(0): tile t + 1 has landed - this wave's requests, a tile old
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 #ifdef CTN_STAMPS
     const unsigned long long s1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -185,23 +182,18 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
     st_nxt = st_nxt == ZST - 1 ? 0 : st_nxt + 1;
     ++t;
   };
+  // (a tile's first fragments read at the end of the tile before - the stage has landed by then: +-0, the other wave
+  // of the SIMD covers that latency already)
   float fa[2][4], fb[2], fy[2][8];
-  if (ZPF) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa[0][i] = smem[h * ZM + kh * (ZM / 2) + l31 + 32 * i];
-    fb[0] = smem[4096 + h * ZU + ub * 32 + l31];
-  }
 
   for (int q = 0; q < a.Q; ++q) {
     // ---- phase 1: Tq[m1 half kh, u-block ub] = sum_k1 E[k1][m1] Xq[k1][u] ------------------------------------
-    auto tile1 = [&](auto last) {                // one phase-1 tile; last: the next tile is a phase-2 tile
+    for (int s = 0; s < T1; ++s) {
       const float* cA = smem + st_cur * ZSTG + h * ZM + kh * (ZM / 2) + l31;       // E image [k1][256]
       const float* cB = smem + st_cur * ZSTG + 4096 + h * ZU + ub * 32 + l31;      // Xq image [k1][128]
-      if (!ZPF) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[0][i] = cA[32 * i];
-        fb[0] = cB[0];
-      }
+      for (int i = 0; i < 4; ++i) fa[0][i] = cA[32 * i];
+      fb[0] = cB[0];
 #pragma unroll
       for (int kk = 0; kk < ZK / 2; ++kk) {
         const int c = kk & 1, nx = c ^ 1;
@@ -209,23 +201,13 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) fa[nx][i] = cA[2 * (kk + 1) * ZM + 32 * i];
           fb[nx] = cB[2 * (kk + 1) * ZU];
-        } else if (ZPF) {                        // the next tile (landed: this tile's barrier is behind us): its first fragments
-          const float* nS = smem + st_nxt * ZSTG;
-          if (!decltype(last)::value) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[0][i] = nS[h * ZM + kh * (ZM / 2) + l31 + 32 * i];
-            fb[0] = nS[4096 + h * ZU + ub * 32 + l31];
-          } else {
-#pragma unroll
-            for (int nb = 0; nb < 8; ++nb) fy[0][nb] = nS[kh * 4096 + (4 * h) * ZM + l31 + 32 * nb];
-          }
         }
         if (kk == bar_at + 1) request_step();   // the cursor moves on in the shadow of this k-step's MFMAs
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i], fb[c], acc1[i], 0, 0, 0);   // D1[m1][u]
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, (ZPF && decltype(last)::value) ? 8 : 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
@@ -234,38 +216,20 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
         if (kk == bar_at) middle();
       }
       advance();
-    };
-    if (ZPF) {
-      for (int s = 0; s + 1 < T1; ++s) tile1(std::false_type{});
-      tile1(std::true_type{});
-    } else {
-      for (int s = 0; s < T1; ++s) tile1(std::false_type{});
     }
     // ---- phase 2: E'[u-block ub, :] += sum over this half's m1 of Tq[m1][u] Yq[m1][n2] -------------------------
 #pragma unroll
     for (int ms = 0; ms < T2; ++ms) {
       // rows 16 ms .. 16 ms + 15 of the half = half of accumulator block ms / 2: its register groups g = 2 (ms & 1), + 1
       const float* cY = smem + st_cur * ZSTG + kh * 4096 + (4 * h) * ZM + l31;      // Yq image [16 rows][256]
-      if (!ZPF) {
 #pragma unroll
-        for (int nb = 0; nb < 8; ++nb) fy[0][nb] = cY[32 * nb];
-      }
+      for (int nb = 0; nb < 8; ++nb) fy[0][nb] = cY[32 * nb];
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {           // k-step (g, e) = (kk / 4, kk % 4): row 8 (kk / 4) + 4 h + e of the tile
         const int c = kk & 1, nx = c ^ 1;
         if (kk + 1 < 8) {
 #pragma unroll
           for (int nb = 0; nb < 8; ++nb) fy[nx][nb] = cY[(8 * ((kk + 1) / 4) + (kk + 1) % 4) * ZM + 32 * nb];
-        } else if (ZPF) {
-          const float* nS = smem + st_nxt * ZSTG;
-          if (ms + 1 < T2) {
-#pragma unroll
-            for (int nb = 0; nb < 8; ++nb) fy[0][nb] = nS[kh * 4096 + (4 * h) * ZM + l31 + 32 * nb];
-          } else {                               // (after the last tile of all: stale floats, never used)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[0][i] = nS[h * ZM + kh * (ZM / 2) + l31 + 32 * i];
-            fb[0] = nS[4096 + h * ZU + ub * 32 + l31];
-          }
         }
         const float tq = acc1[ms / 2][4 * (2 * (ms & 1) + kk / 4) + kk % 4];
         if (kk == bar_at + 1) request_step();
