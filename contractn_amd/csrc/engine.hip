@@ -149,6 +149,8 @@ struct Exec {
   double* d_sweep_a = nullptr;         // [R][S][J]
   float* d_sweep_s = nullptr;          // [R][S][J]
   double* d_sweep_z = nullptr;         // [R][S]
+  double* d_sweep_la = nullptr;        // [R][S][J] logs of d_sweep_a / d_sweep_s
+  double* d_sweep_ls = nullptr;
   std::vector<int32_t> launched_tile;  // per step: (tile rows << 16 | tile columns) of the last enqueue's MFMA kernel, else 0
   char* d_ws = nullptr;
   int32_t* d_tables = nullptr;
@@ -206,7 +208,7 @@ struct Exec {
                     (void*)d_log, (void*)d_resc, (void*)d_logs, (void*)d_chain, d_ones, (void*)d_stepP, (void*)d_stepNumel,
                     (void*)d_stepOff, (void*)d_stepSlots,
                     (void*)d_stage_in, (void*)d_stage_out, (void*)d_group_args, (void*)d_sweep_ids, (void*)d_sweep_off,
-                    (void*)d_sweep_slots, (void*)d_sweep_a, (void*)d_sweep_s, (void*)d_sweep_z})
+                    (void*)d_sweep_slots, (void*)d_sweep_a, (void*)d_sweep_s, (void*)d_sweep_z, (void*)d_sweep_la, (void*)d_sweep_ls})
       if (p) (void)hipFree(p);
     if (h_pack) (void)hipHostFree(h_pack);
     if (h_group_args) (void)hipHostFree(h_group_args);
@@ -708,11 +710,13 @@ static int exec_launch_steps(Exec* E) {
         }
         hipLaunchKernelGGL(k_sweep_f32, dim3((unsigned)sd.J, (unsigned)R), dim3(512), 0, E->stream, w);
         const double numel = (double)P.tensors[st.out].numel;
-        hipLaunchKernelGGL(k_sweep_z, dim3((unsigned)S, (unsigned)R), dim3(256), 0, E->stream, (const double*)E->d_sweep_a,
-                           (const float*)E->d_sweep_s, S, sd.J, numel, E->d_sweep_z);
+        hipLaunchKernelGGL(k_sweep_logs, dim3((unsigned)S, (unsigned)R), dim3(256), 0, E->stream, (const double*)E->d_sweep_a,
+                           (const float*)E->d_sweep_s, S, sd.J, E->d_sweep_la, E->d_sweep_ls);
+        hipLaunchKernelGGL(k_sweep_z, dim3((unsigned)S, (unsigned)R), dim3(256), 0, E->stream, (const double*)E->d_sweep_la,
+                           (const double*)E->d_sweep_ls, S, sd.J, numel, E->d_sweep_z);
         SweepFinish f{};
         f.ptrs = E->d_ptrs; f.n_tensors = E->n_tensors; f.idOut = st.out; f.S = S; f.J = sd.J; f.R = R;
-        f.ldOut = sd.ldOut; f.Z = E->d_sweep_z; f.rec_s = E->d_sweep_s; f.part_off = E->d_sweep_off;
+        f.ldOut = sd.ldOut; f.Z = E->d_sweep_z; f.ls = E->d_sweep_ls; f.part_off = E->d_sweep_off;
         f.part_slots = E->d_sweep_slots; f.partials = E->d_partials; f.numel = numel;
         f.min_norm = P.stabilize ? P.min_norm : INFINITY;
         hipLaunchKernelGGL(k_sweep_finish, dim3((unsigned)sd.J, (unsigned)R), dim3(256), 0, E->stream, f);
@@ -1470,7 +1474,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   // a sweep: at least half a chip of row blocks, or CTN_SWEEP=1
   if (!P.chain && E.sw.sweep != 0 && P.stabilize) {
     Exec::SweepDesc sd;
-    if (sweep_match(P, &sd) && (E.sw.sweep == 1 || (sd.steps.size() >= 4 && (int64_t)sd.J * replicas * 2 >= E.n_cu))) {
+    if (sweep_match(P, &sd) && (int)sd.steps.size() <= kSweepMaxSites && (E.sw.sweep == 1 || (sd.steps.size() >= 4 && (int64_t)sd.J * replicas * 2 >= E.n_cu))) {
       E.sweep = sd;
       const int S = (int)sd.steps.size();
       E.sweep_role.assign(P.n_steps, 0);
@@ -1492,6 +1496,8 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
       HIPCHECK_X(hipMalloc((void**)&E.d_sweep_a, nrec * 8));
       HIPCHECK_X(hipMalloc((void**)&E.d_sweep_s, nrec * 4));
       HIPCHECK_X(hipMalloc((void**)&E.d_sweep_z, (size_t)replicas * S * 8));
+      HIPCHECK_X(hipMalloc((void**)&E.d_sweep_la, nrec * 8));
+      HIPCHECK_X(hipMalloc((void**)&E.d_sweep_ls, nrec * 8));
     }
   }
   // leaf groups: runs of consecutive plain streaming steps on network inputs, same kernel variant (see Exec::LeafGroup)

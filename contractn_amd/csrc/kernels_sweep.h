@@ -40,7 +40,7 @@ namespace ctn {
 // when its norm exceeds min_norm, R_s = exp(Z_s) then, else R_s = R_{s-1}); k_sweep_finish writes them where the
 // per-step launches would have left their abs-sums, and brings the last site's rows - stored by the sweep with each
 // block's own scale - to the one scale the reference's stored tensor has.  Same numbers as the per-site launches up
-// to rounding; three launches instead of one per site.
+// to rounding; four launches instead of one per site.
 //
 // Conditions (engine.hip, sweep_match): fp32, |l| = |r| = 256, |p| = 4, rows a multiple of 16, W_s and x_s network
 // inputs with r and p unit-stride, E row-major.
@@ -178,8 +178,11 @@ __global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
             }
           wrequest(wq[4 * gb + t], t);
           if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the next group's B operands first
-          __builtin_amdgcn_sched_group_barrier(0x008, 4 * SWP, 0);         // this k-step's MFMAs, then its queue slot's requests
-          __builtin_amdgcn_sched_group_barrier(0x020, SWP, 0);
+#pragma unroll
+          for (int p = 0; p < SWP; ++p) {      // a request after every four MFMAs (all four behind the sixteen: +5 % time)
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
         }
         ef = en;
       }
@@ -283,22 +286,34 @@ __global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
 #endif
 }
 
-// Z_s = log of the whole tensor's mean |.| after site s of a sweep, from the blocks' records (see k_sweep_f32).
-// grid (S, R), 256 threads; fixed-order sums.
-__global__ __launch_bounds__(256) void k_sweep_z(const double* __restrict__ rec_a, const float* __restrict__ rec_s, int S, int J,
+// The bookkeeping behind a sweep: three short launches.  (Double-precision log / exp are long dependent chains: a thread
+// that walks the sites and takes one of them per site spends 70 us on a 100-site chain; every transcendental below is
+// evaluated once, in parallel, and the walks over the sites only add and compare.)
+//
+// k_sweep_logs: la[s][j] = log a[s][j] (-inf for an all-zero block), ls[s][j] = log s[s][j].  grid (S, R), 256 threads.
+__global__ __launch_bounds__(256) void k_sweep_logs(const double* __restrict__ rec_a, const float* __restrict__ rec_s, int S, int J,
+                                                    double* __restrict__ la, double* __restrict__ ls) {
+  const size_t base = ((size_t)blockIdx.y * S + blockIdx.x) * J;
+  for (int j = threadIdx.x; j < J; j += 256) {
+    const double av = rec_a[base + j];
+    la[base + j] = av > 0.0 ? log(av) : -INFINITY;
+    ls[base + j] = log((double)rec_s[base + j]);
+  }
+}
+
+// k_sweep_z: Z_s = log of the whole tensor's mean |.| after site s, a log-sum-exp over the blocks of
+// la[s][j] + sum_{i < s} ls[i][j] (see k_sweep_f32).  grid (S, R), 256 threads; fixed-order sums.
+__global__ __launch_bounds__(256) void k_sweep_z(const double* __restrict__ la, const double* __restrict__ ls, int S, int J,
                                                  double numel, double* __restrict__ Z) {
   __shared__ double red[4];
   const int s = blockIdx.x, r = blockIdx.y;
-  const double* ra = rec_a + (size_t)r * S * J;
-  const float* rs = rec_s + (size_t)r * S * J;
-  // a block's term: log a[s][j] + sum_{i < s} log s[i][j]
+  const double* pa = la + ((size_t)r * S + s) * J;
+  const double* ps = ls + (size_t)r * S * J;
   double mx = -INFINITY;
   for (int j = threadIdx.x; j < J; j += 256) {
     double g = 0.0;
-    for (int i = 0; i < s; ++i) g += log((double)rs[(size_t)i * J + j]);
-    const double av = ra[(size_t)s * J + j];
-    const double t = av > 0.0 ? log(av) + g : -INFINITY;
-    mx = fmax(mx, t);
+    for (int i = 0; i < s; ++i) g += ps[(size_t)i * J + j];
+    mx = fmax(mx, pa[j] + g);
   }
 #pragma unroll
   for (int of = 32; of > 0; of >>= 1) mx = fmax(mx, __shfl_xor(mx, of, 64));
@@ -313,48 +328,61 @@ __global__ __launch_bounds__(256) void k_sweep_z(const double* __restrict__ rec_
   double sum = 0.0;
   for (int j = threadIdx.x; j < J; j += 256) {
     double g = 0.0;
-    for (int i = 0; i < s; ++i) g += log((double)rs[(size_t)i * J + j]);
-    const double av = ra[(size_t)s * J + j];
-    if (av > 0.0) sum += exp(log(av) + g - mx);
+    for (int i = 0; i < s; ++i) g += ps[(size_t)i * J + j];
+    const double t = pa[j] + g;
+    if (t > -INFINITY) sum += exp(t - mx);
   }
   const double tot = block_sum(sum, red);
   if (threadIdx.x == 0) Z[(size_t)r * S + s] = mx + log(tot) - log(numel);
 }
 
-// The reference's rescale factors of a sweep's steps from the Z_s, and the last site's rows at the common scale.
-// grid (J, R), 256 threads.  part_off[s] = first slot of chain step s in the partials buffer (per replica: slots[s]).
+// k_sweep_finish: the reference's rescale factors of a sweep's steps from the Z_s, and the last site's rows at the
+// common scale.  grid (J, R), 256 threads.
 struct SweepFinish {
   void* const* ptrs;
   int32_t n_tensors, idOut, S, J, R;
   int64_t ldOut;
   const double* Z;           // [R][S]
-  const float* rec_s;        // [R][S][J]
-  const int64_t* part_off;   // [S]: d_partials offset (in doubles) of the step's region for replica 0 = off[s] * R
-  const int32_t* part_slots; // [S]
+  const double* ls;          // [R][S][J] log of the scales the blocks applied
+  const int64_t* part_off;   // [S]: the step's region in the partials buffer starts at part_off[s] * R doubles
+  const int32_t* part_slots; // [S]: slots per replica of that region
   double* partials;
   double numel, min_norm;
 };
 
+constexpr int kSweepMaxSites = 1024;
+
 __global__ __launch_bounds__(256) void k_sweep_finish(SweepFinish f) {
+  __shared__ double lognorm[kSweepMaxSites];
+  __shared__ double fac_log;
   const int j = blockIdx.x, r = blockIdx.y;
   const double* Z = f.Z + (size_t)r * f.S;
-  // the reference's recurrence (einsum.py:97-106 over the chain's steps): norm_s = numel exp(Z_s) / R_{s-1};
-  // rescaled iff norm_s > min_norm, then R_s = exp(Z_s)
-  double logR = 0.0, logR_before_last = 0.0;
-  for (int s = 0; s < f.S; ++s) {
-    const double norm = Z[s] == -INFINITY ? 0.0 : f.numel * exp(Z[s] - logR);
-    if (s + 1 == f.S) logR_before_last = logR;
-    if (j == 0) {                             // what the step's own launch would have left: its abs-sum (slot 0)
-      double* dst = f.partials + (size_t)f.part_off[s] * f.R + (size_t)r * f.part_slots[s];
-      for (int i = threadIdx.x; i < f.part_slots[s]; i += 256) dst[i] = i == 0 ? norm : 0.0;
+  if (threadIdx.x == 0) {
+    // the reference's recurrence (einsum.py:97-106 over the chain's steps), in logs: norm_s = numel exp(Z_s) / R_{s-1};
+    // rescaled iff norm_s > min_norm, then R_s = exp(Z_s)
+    const double lnum = log(f.numel), lmin = f.min_norm > 0.0 ? log(f.min_norm) : -INFINITY;
+    double logR = 0.0, logR_before_last = 0.0;
+    for (int s = 0; s < f.S; ++s) {
+      const double ln = Z[s] == -INFINITY ? -INFINITY : lnum + Z[s] - logR;
+      if (s + 1 == f.S) logR_before_last = logR;
+      lognorm[s] = ln;
+      if (ln > lmin) logR = Z[s];
     }
-    if (norm > f.min_norm) logR = Z[s];
+    // this block's rows of the last site: V = W exp(g[j][S - 2]); the reference's stored tensor = V / R_{S-2}
+    double g = 0.0;
+    const double* ps = f.ls + (size_t)r * f.S * f.J + j;
+    for (int i = 0; i + 1 < f.S; ++i) g += ps[(size_t)i * f.J];
+    fac_log = g - logR_before_last;
   }
-  // this block's rows of the last site: V = W exp(g[j][S - 2]); stored tensor of the reference = V / R_{S-2}
-  double g = 0.0;
-  const float* rs = f.rec_s + (size_t)r * f.S * f.J + j;
-  for (int i = 0; i + 1 < f.S; ++i) g += log((double)rs[(size_t)i * f.J]);
-  const float fac = (float)exp(g - logR_before_last);
+  __syncthreads();
+  if (j == 0) {                               // what each step's own launch would have left: its abs-sum, in slot 0
+    for (int s = threadIdx.x; s < f.S; s += 256) {
+      double* dst = f.partials + (size_t)f.part_off[s] * f.R + (size_t)r * f.part_slots[s];
+      dst[0] = lognorm[s] == -INFINITY ? 0.0 : exp(lognorm[s]);
+      for (int i = 1; i < f.part_slots[s]; ++i) dst[i] = 0.0;
+    }
+  }
+  const float fac = (float)exp(fac_log);
   float* out = (float*)f.ptrs[(size_t)r * f.n_tensors + f.idOut] + (int64_t)(SWR * j) * f.ldOut;
   for (int i = threadIdx.x; i < SWR * SWD / 4; i += 256) {
     const int row = i / (SWD / 4), c4 = i - row * (SWD / 4);

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerate the evidence under profiles/ on a GPU box (run from the repo root):
-#   gpurun --timeout 1200 -- 'bash tools/regen_profiles.sh r02'      then, back in the container,
-#   python profiles/make_summary.py r02 gpurun_out/prof_r02 gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq gpurun_out/bench_default.json
-#   cp gpurun_out/bench_default.json profiles/r02_bench.json; cp gpurun_out/bench_f64.json profiles/r02_bench_f64.json
+#   gpurun --timeout 1200 -- 'bash tools/regen_profiles.sh r03'      then, back in the container,
+#   python profiles/make_summary.py r03 gpurun_out/prof_r03 gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq gpurun_out/bench_default.json
+#   cp gpurun_out/bench_default.json profiles/r03_bench.json; cp gpurun_out/bench_f64.json profiles/r03_bench_f64.json
 # Counters are collected in their own passes (no trace domains next to --pmc); the program itself follows `--`.
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 mkdir -p gpurun_out
 B="--no-cpu-baseline --no-peps"
 R=$GRAFT_REPO_ROOT
