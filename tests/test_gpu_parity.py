@@ -1234,3 +1234,51 @@ def test_sweep_of_a_batched_mps_matches_the_per_site_launches(sites, batch, repl
         assert abs(float(np.mean(np.abs(res["1"][0][r]))) - 1.0) < 1e-5 and abs(float(res["1"][1][r]) - float(rc)) <= 1e-4
     monkeypatch.delenv("CTN_SWEEP")
     E.clear_caches()
+
+
+def test_sweep_steps_aside_in_eager_mode_and_survives_an_eager_repeat(monkeypatch):
+    """An executor that walks a batched MPS as one k_sweep_f32 launch: (1) forced into the eager rescale mode it takes
+    the per-site launches again (the sweep keeps its own products in range, but eager mode means the reference's literal
+    order for EVERY step) and gives the lazy run's numbers to rounding; (2) every operand 1e9 times larger: whether the
+    fetch has to repeat the contraction eagerly or not, the value is the oracle's; (3) the next, tame operands run
+    lazily - with the sweep - again, to the same bits as before."""
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from oracle import cpu_ref
+    from tests import networks as nets
+
+    sites, batch, bond, phys = 7, 64, 256, 4
+    monkeypatch.setenv("CTN_SWEEP", "1")
+    E.clear_caches()
+    tn, inputs = nets.batched_mps(TN, sites, bond, phys, batch, dtype=np.float32, seed=4)
+    path = ssa_to_linear(nets.batched_mps_path(sites), 2 * sites)
+    shapes = [np.asarray(o).shape for o in E.make_arg_packer(tn)(tn.params, inputs)]
+    rng = np.random.default_rng(11)
+    tame = [(rng.standard_normal(sh) * (0.25 if sh == (batch, phys) else 1.0 / 16.0)).astype(np.float32) for sh in shapes]
+
+    def value(t, c):
+        return np.asarray(t, dtype=np.float64) * np.exp(float(c))
+
+    lazy = E.BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=1)
+    t_l, c_l = lazy.run_host([tame])
+    assert (16, 1024) in lazy.executor.step_tiles() and lazy.executor.eager_reruns() == 0
+    eager = E.BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=1)
+    eager.executor.set_rescale_mode(1)
+    t_e, c_e = eager.run_host([tame])
+    assert (16, 1024) not in eager.executor.step_tiles() and eager.executor.eager_reruns() == 0
+    a, b = value(t_l[0], c_l[0]), value(t_e[0], c_e[0])
+    assert np.max(np.abs(a - b)) <= 2e-5 * np.max(np.abs(b))
+    # (2) every tensor 1e9 times larger (the reference, like the eager mode, normalises after every step)
+    huge = [(o * np.float32(1e9)).astype(np.float32) for o in tame]
+    t_h, c_h = lazy.run_host([huge])
+    rt, rc = cpu_ref.contract(tn.einsum_str, *huge, path=path, split_format=True)
+    assert np.all(np.isfinite(t_h)) and abs(float(c_h[0]) - float(rc)) <= 1e-3
+    assert np.max(np.abs(t_h[0] - np.asarray(rt))) <= 1e-3 * np.max(np.abs(np.asarray(rt)))
+    # (3) tame operands again: the same bits as the first lazy run, sweep and all
+    reruns = lazy.executor.eager_reruns()
+    t_2, c_2 = lazy.run_host([tame])
+    assert np.array_equal(t_2, t_l) and np.array_equal(c_2, c_l) and lazy.executor.eager_reruns() == reruns
+    assert (16, 1024) in lazy.executor.step_tiles()
+    lazy.executor.close(); eager.executor.close()
+    monkeypatch.delenv("CTN_SWEEP")
+    E.clear_caches()
