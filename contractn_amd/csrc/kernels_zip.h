@@ -85,29 +85,35 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
   constexpr int T2 = (ZM / 2) / ZK;            // phase-2 tiles per q: 16 rows of each m1 half at a time
   const int TQ = T1 + T2, TT = a.Q * TQ;
 
-  // the LDS-DMA requests of the next tile not yet asked for (this wave's share): phase 1: rows 2 w, 2 w + 1 of E (1 KiB
-  // each) and of Xq (both in one request: lanes 0-31 / 32-63); phase 2: rows 4 ub .. 4 ub + 3 of this wave's m1 half of
-  // Yq.  The cursor walks the tiles in order with running pointers - a handful of scalar adds per request: both waves
-  // of a SIMD come out of the tile's barrier together, and whatever they do before their next MFMA is matrix-pipe idle
+  // the LDS-DMA requests of the next tile not yet asked for.  The cursor walks the tiles in order with running pointers -
+  // a handful of scalar adds per request: both waves of a SIMD come out of the tile's barrier together, and whatever they do before their next MFMA is matrix-pipe idle
   // time (~100 scalar instructions of index arithmetic here cost 8 % of the kernel).
   // (the pointers are wave-uniform - scalar registers; a lane's own offset is a 32-bit number added by the instruction)
-  const float* const rE0 = E + (int64_t)(2 * w) * a.ldE;
+  // Only the four waves of the first m1 half issue requests - each for both halves: the two waves of a SIMD (w, w + 4)
+  // do not interleave, the older one runs ahead and parks at the tile's barrier (a third of its time); an LDS-DMA
+  // instruction costs its wave ~60 cycles, and with every wave issuing its share right behind the barrier both waves
+  // of a SIMD paid them at the same moment with no MFMA queued.  Now the younger wave goes straight on with its MFMAs.
+  const float* const rE0 = E + (int64_t)(4 * ub) * a.ldE;
   const float* rE = rE0;
-  const float* rX = X + (int64_t)(2 * w) * a.ldXk;
-  const float* rY = Y + (int64_t)(kh * (ZM / 2) + 4 * ub) * a.ldYm;
+  const float* rX = X + (int64_t)(4 * ub) * a.ldXk;
+  const float* rY = Y + (int64_t)(4 * ub) * a.ldYm;
   const int offE = 4 * lane, offX = h * (int)a.ldXk + 4 * l31;
   const int64_t stepE = (int64_t)ZK * a.ldE, stepX = (int64_t)ZK * a.ldXk, stepY = (int64_t)ZK * a.ldYm;
   const int64_t nextX = a.ldXq - (int64_t)a.K1 * a.ldXk, nextY = a.ldYq - (int64_t)(ZM / 2) * a.ldYm;
+  const int64_t halfY = (int64_t)(ZM / 2) * a.ldYm;
   int rq_s = 0, rq_left = TT;
   auto request_issue = [&](int stage) {
     float* st = smem + stage * ZSTG;
-    if (rq_s < T1) {
-      glds16(rE + offE, st + (2 * w) * ZM);
-      glds16(rE + a.ldE + offE, st + (2 * w + 1) * ZM);
-      glds16(rX + offX, st + 4096 + (2 * w) * ZU);
-    } else {
+    if (rq_s < T1) {             // rows 4 ub .. 4 ub + 3 of E (1 KiB each) and of Xq (two rows per request: lanes 0-31 / 32-63)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) glds16(rY + i * a.ldYm + offE, st + kh * 4096 + (4 * ub + i) * ZM);
+      for (int i = 0; i < 4; ++i) glds16(rE + i * a.ldE + offE, st + (4 * ub + i) * ZM);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16(rX + 2 * i * a.ldXk + offX, st + 4096 + (4 * ub + 2 * i) * ZU);
+    } else {                     // rows 4 ub .. 4 ub + 3 of both m1 halves of Yq
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(rY + hf * halfY + i * a.ldYm + offE, st + hf * 4096 + (4 * ub + i) * ZM);
     }
   };
   auto request_step = [&]() {                  // (plain selects: the running pointers stay in scalar registers)
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
 
 #pragma unroll
   for (int i = 0; i < ZST - 1; ++i) {
-    request_issue(i);
+    if (kh == 0) request_issue(i);
     request_step();
   }
   double pve = 0.0;
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
     wait_vm += s1 - s0;
     wait_bar += s2 - s1;
 #endif
-    if (rq_left > 0) request_issue(st_req);
+    if (kh == 0 && rq_left > 0) request_issue(st_req);
     __builtin_amdgcn_sched_barrier(0);
   };
   auto advance = [&]() {
