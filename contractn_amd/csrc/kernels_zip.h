@@ -86,9 +86,10 @@ __global__ __launch_bounds__(512, 1) void k_zip_f32(ZipArgs a) {
   const int TQ = T1 + T2, TT = a.Q * TQ;
 
   // the LDS-DMA requests of the next tile not yet asked for.  The cursor walks the tiles in order with running pointers -
-  // a handful of scalar adds per request: both waves of a SIMD come out of the tile's barrier together, and whatever they do before their next MFMA is matrix-pipe idle
-  // time (~100 scalar instructions of index arithmetic here cost 8 % of the kernel).
-  // (the pointers are wave-uniform - scalar registers; a lane's own offset is a 32-bit number added by the instruction)
+  // a handful of scalar adds per request: both waves of a SIMD come out of the tile's barrier together, and whatever
+  // they do before their next MFMA is matrix-pipe idle time (~100 scalar instructions of index arithmetic here cost
+  // 8 % of the kernel).  The pointers are wave-uniform - scalar registers; a lane's own offset is a 32-bit number added
+  // by the instruction.
   // Only the four waves of the first m1 half issue requests - each for both halves: the two waves of a SIMD (w, w + 4)
   // do not interleave, the older one runs ahead and parks at the tile's barrier (a third of its time); an LDS-DMA
   // instruction costs its wave ~60 cycles, and with every wave issuing its share right behind the barrier both waves
