@@ -196,7 +196,8 @@ def test_cfg5_bond16_sliced_vs_oracle_on_the_large_tile_kernels():
 # ---- config 3b: the paper's ML workload at its full size --------------------------------------------------------------
 def test_cfg3b_full_size_batched_mps_vs_oracle_on_a_subset_of_the_batch():
     """4096 inputs through ONE 100-site MPS (D = 256, d = 4) hanging on a batch hyperedge (BASELINE configs[2] in its
-    batched form, SURVEY.md 8d cfg 3b; 212 GFLOP): every interior site is one launch (`epilogue_sum`), nothing larger
+    batched form, SURVEY.md 8d cfg 3b; 212 GFLOP): every interior site is one epilogue-summed step of the plan (`epilogue_sum`;
+    all 98 of them go out as ONE k_sweep_f32 launch), nothing larger
     than B x D is ever stored, and - batch independence - outputs 0..31 and 4064..4095 equal the CPU oracle run on
     those 64 inputs alone (same path), to the north_star's fp32 tolerance."""
     import torch
