@@ -224,6 +224,29 @@ def _executor_for(plan, replicas=1, device=0, stream=None):
     return ex
 
 
+class _locked_executor:
+    """``with _locked_executor(plan, ...) as ex``: the cached executor of this thread, locked and ALIVE.  Eviction is
+    global while the cache is per thread: another thread's insertion can evict - and close - this thread's executor
+    between the lookup and the lock.  A closed executor (handle gone) is simply looked up again."""
+
+    def __init__(self, plan, replicas=1, device=0, stream=None):
+        self.args = (plan, replicas, device, stream)
+        self.ex = None
+
+    def __enter__(self):
+        while True:
+            ex = _executor_for(*self.args)
+            ex.lock.acquire()
+            if getattr(ex, "is_open", lambda: True)():
+                self.ex = ex
+                return ex
+            ex.lock.release()          # closed under our feet: it is out of the table already
+
+    def __exit__(self, *exc):
+        self.ex.lock.release()
+        return False
+
+
 def clear_caches():
     """Drop every cached executor (device memory), native plan and contraction path."""
     with _EXECUTOR_LRU_LOCK:
@@ -333,8 +356,7 @@ def _core_contract(operands, contract_list, backend="numpy", **einsum_kwargs):
     plan = _native_plan(contract_list, shapes, dtype.name)
     if backend == "torch":
         return _run_torch(plan, operands, dtype)
-    ex = _executor_for(plan, 1)
-    with ex.lock:
+    with _locked_executor(plan, 1) as ex:
         outs, _dev_log, resc = ex.run_host([operands])
     log_scale = accumulate_log_scale(resc[0], dtype)
     return outs[0], log_scale
@@ -471,8 +493,7 @@ def _core_contract_complex(operands, contract_list, shapes, dtype, backend):
             else:
                 host.append(np.ascontiguousarray(o, dtype=dtype))
     host += [_CSTRUCT.astype(dtype)] * n_s
-    ex = _executor_for(plan, 1)
-    with ex.lock:
+    with _locked_executor(plan, 1) as ex:
         outs, _dev_log, resc = ex.run_host([host])
     log_scale = accumulate_log_scale(resc[0], dtype, register_dtype=dtype if backend == "torch" else np.float64)
     res = outs[0]
@@ -499,9 +520,8 @@ def _run_torch(plan, operands, dtype):
             "the HIP engine does not build an autograd graph: detach() the operands or contract under "
             "torch.no_grad()")
     if not all(o.is_cuda for o in operands):
-        ex = _executor_for(plan, 1)
         host = [o.detach().cpu().numpy() for o in operands]
-        with ex.lock:
+        with _locked_executor(plan, 1) as ex:
             outs, _dev_log, resc = ex.run_host([host])
         log_scale = accumulate_log_scale(resc[0], dtype, register_dtype=dtype)
         return torch.from_numpy(np.array(outs[0])), torch.tensor(float(log_scale), dtype=tdt)   # (a closed network: 0-d)
@@ -516,8 +536,7 @@ def _run_torch(plan, operands, dtype):
         # torch is on the legacy default stream (handle 0), which cannot be handed to the executor:
         # it runs on its own non-blocking stream, so wait for the producers of the operands first
         tstream.synchronize()
-    ex = _executor_for(plan, 1, device=dev.index or 0, stream=stream)
-    with ex.lock:
+    with _locked_executor(plan, 1, device=dev.index or 0, stream=stream) as ex:
         ex.enqueue([o.data_ptr() for o in ops], [out.data_ptr()])
         _dev_log, resc = ex.fetch()
     # the torch backend's register: the tensor dtype, sequential adds in it (reference einsum.py:338; App. A)

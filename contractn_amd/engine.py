@@ -454,6 +454,10 @@ class Executor:
         _check(self._lib.ctn_exec_step_ms(self._h, _ptr(ms, C.c_float)))
         return self.plan.in_caller_order(ms)
 
+    def is_open(self):
+        """False once close() has run (a cached executor evicted by another thread): look it up again."""
+        return bool(getattr(self, "_h", None))
+
     def close(self):
         lock = getattr(self, "lock", None)
         if lock is None:      # __init__ failed before the handle existed

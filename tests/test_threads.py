@@ -93,6 +93,43 @@ def test_lru_eviction_closes_executors_and_is_bounded(monkeypatch):
     assert all(ex.closed for ex in ProbeExecutor.created)
 
 
+def test_an_executor_evicted_between_lookup_and_lock_is_looked_up_again(monkeypatch):
+    """Eviction is global, the cache per thread: with more live (thread, plan) pairs than slots, another thread's insertion
+    can close the executor a thread has just looked up.  Many threads on a two-slot cache, each with its own plan: no run
+    ever reaches a closed executor (the probe asserts that), every result arrives."""
+    E.clear_caches()
+    ProbeExecutor.created = []
+
+    class ClosableProbe(ProbeExecutor):
+        def is_open(self):
+            return not self.closed
+
+    monkeypatch.setattr(engine, "Executor", ClosableProbe)
+    monkeypatch.setattr(E, "MAX_CACHED_EXECUTORS", 2)
+    errors = []
+    start = threading.Barrier(6)
+
+    def worker(n):
+        try:
+            a, b = np.ones((n, 3)), np.ones((3, 2))
+            clist = E._contract_path("ab,bc->ac", ((n, 3), (3, 2)), optimize="auto", memory_limit=None, use_blas=True)
+            start.wait()
+            for _ in range(40):
+                t, _c = E._core_contract([a, b], clist, "numpy")
+                assert t.shape == (n, 2)
+        except Exception as exc:  # noqa: BLE001 - reported below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(n,)) for n in range(2, 8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(ProbeExecutor.created) > 6                       # evictions did happen
+    E.clear_caches()
+
+
 def test_torch_operands_that_require_grad_are_refused():
     """The reference's torch backend is differentiable; this engine is not - it must say so instead of
     returning a result without a graph."""
