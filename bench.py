@@ -243,7 +243,7 @@ def batched_secondary(args, result, world, rank, backend, dev):
         bc.executor.set_timing(0)
         dom = [i for i, x in enumerate(infos) if x["epilogue_sum"] > 0]
         tiles = bc.executor.step_tiles()
-        sweep = [i for i, t in enumerate(tiles) if t == (16, 1024)]
+        sweep = [i for i, t in enumerate(tiles) if t[0] == 16 and t[1] >= 128]     # (16, bond x phys): k_sweep_f32
         if sweep:
             # the interior sites went out as ONE launch (k_sweep_f32) at the position of the last of them; its events
             # also bracket the three bookkeeping launches behind it (k_sweep_logs, k_sweep_z, k_sweep_finish)

@@ -139,7 +139,7 @@ struct Exec {
     bool on = false;
     std::vector<int> steps;          // the members' step indices, in chain order
     int64_t ldIn = 0, ldOut = 0, ldWl = 0, ldWp = 0, ldX = 0;
-    int J = 0;
+    int J = 0, M = 0, D = 0, Pd = 0;     // row blocks, rows, bond and physical dimension
   };
   SweepDesc sweep;
   std::vector<char> sweep_role;
@@ -573,35 +573,36 @@ static bool zip_match(const Plan& P, int s2, Exec::ZipDesc* z) {
 
 // Is step s an epilogue-summed GEMM step that k_sweep_f32 can take as one site of a sweep?  Checked on the plan's own
 // offset tables: E row-major [b][l], W[l][p][r] with r unit-stride, x[b][p] with p unit-stride, result rows [b][r].
-struct SweepShape { int64_t ldA = 0, ldC = 0, ldWl = 0, ldWp = 0, ldX = 0, M = 0; };
+struct SweepShape { int64_t ldA = 0, ldC = 0, ldWl = 0, ldWp = 0, ldX = 0, M = 0; int D = 0, Pd = 0; };
 static bool sweep_step_shape(const Plan& P, int s, SweepShape* sh) {
   const Step& st = P.steps[s];
-  if (P.dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.epw != SWP || st.Bt != 1 || st.K != SWD ||
-      st.N != (int64_t)SWD * SWP || st.M % SWR != 0 || st.collapse || s + 1 >= P.n_steps)
+  const int D = (int)st.K, Pd = st.epw;
+  if (P.dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || (Pd != 2 && Pd != 4) || st.Bt != 1 ||
+      (st.K != 64 && st.K != 128 && st.K != 256 && st.K != 512) || st.N != (int64_t)D * Pd || st.collapse || s + 1 >= P.n_steps)
     return false;
   if (st.rhs < 0 || st.rhs >= P.n_inputs || st.lhs2 < 0 || st.lhs2 >= P.n_inputs) return false;   // W, x: network inputs
   const int32_t* T = P.tables.data();
   const int32_t *omA = T + st.t.omA, *okA = T + st.t.okA, *onB = T + st.t.onB, *okB = T + st.t.okB, *omC = T + st.t.omC,
                 *onC = T + st.t.onC, *omX = T + st.t.omA2;
   const int64_t M = st.M;
-  const int64_t ldA = M > 1 ? omA[1] : SWD, ldC = M > 1 ? omC[1] : SWD, ldX = M > 1 ? omX[1] : SWP, ldWl = okB[1];
+  const int64_t ldA = M > 1 ? omA[1] : D, ldC = M > 1 ? omC[1] : D, ldX = M > 1 ? omX[1] : Pd, ldWl = okB[1];
   for (int64_t m = 0; m < M; ++m)
     if (omA[m] != m * ldA || omC[m] != m * ldC || omX[m] != m * ldX) return false;
-  for (int k = 0; k < SWD; ++k)
+  for (int k = 0; k < D; ++k)
     if (okA[k] != k || okB[k] != (int64_t)k * ldWl) return false;
   int64_t ldWp = INT64_MAX;
-  for (int n = 0; n < SWD * SWP; ++n)
-    if (onB[n] >= SWD) ldWp = std::min<int64_t>(ldWp, onB[n]);
+  for (int n = 0; n < D * Pd; ++n)
+    if (onB[n] >= D) ldWp = std::min<int64_t>(ldWp, onB[n]);
   if (ldWp == INT64_MAX) return false;
-  std::vector<char> seen((size_t)SWD * SWP, 0);
-  for (int n = 0; n < SWD * SWP; ++n) {
+  std::vector<char> seen((size_t)D * Pd, 0);
+  for (int n = 0; n < D * Pd; ++n) {
     const int64_t off = onB[n], pp = off / ldWp, rr = off % ldWp;
-    if (off < 0 || pp >= SWP || rr >= SWD || onC[n] != rr || seen[(size_t)(pp * SWD + rr)]) return false;
-    seen[(size_t)(pp * SWD + rr)] = 1;
+    if (off < 0 || pp >= Pd || rr >= D || onC[n] != rr || seen[(size_t)(pp * D + rr)]) return false;
+    seen[(size_t)(pp * D + rr)] = 1;
   }
-  if (ldA < SWD || ldC < SWD || ldA % 4 || ldC % 4 || ldX % 4 || ldX < SWP || ldWl % 4 || ldWp % 4 || ldWl < SWD) return false;
-  if (((SWD / 2 + 12) * ldWl + 3 * ldWp + SWD) * 4 >= ((int64_t)1 << 31)) return false;   // a lane's offsets into a core: 32 bits
-  sh->ldA = ldA; sh->ldC = ldC; sh->ldWl = ldWl; sh->ldWp = ldWp; sh->ldX = ldX; sh->M = M;
+  if (ldA < D || ldC < D || ldA % 4 || ldC % 4 || ldX % Pd || ldX < Pd || ldWl % 4 || ldWp % 4 || ldWl < D) return false;
+  if (((D + 12) * ldWl + 3 * ldWp + D) * 4 >= ((int64_t)1 << 31)) return false;   // a lane's offsets into a core: 32 bits
+  sh->ldA = ldA; sh->ldC = ldC; sh->ldWl = ldWl; sh->ldWp = ldWp; sh->ldX = ldX; sh->M = M; sh->D = D; sh->Pd = Pd;
   return true;
 }
 
@@ -621,8 +622,8 @@ static bool sweep_match(const Plan& P, Exec::SweepDesc* d) {
         continue;
       // the consumer of the run's last result: a member if it has the same shape and takes it as its E
       if (P.steps[s].kernel == CTN_KERNEL_FUSED) continue;   // (the marker of the GEMM the member absorbed)
-      if (P.steps[s].lhs == P.steps[run.back()].out && sweep_step_shape(P, s, &cur) && cur.M == first.M &&
-          cur.ldWl == first.ldWl && cur.ldWp == first.ldWp && cur.ldX == first.ldX && cur.ldA == last.ldC) {
+      if (P.steps[s].lhs == P.steps[run.back()].out && sweep_step_shape(P, s, &cur) && cur.M == first.M && cur.D == first.D &&
+          cur.Pd == first.Pd && cur.ldWl == first.ldWl && cur.ldWp == first.ldWp && cur.ldX == first.ldX && cur.ldA == last.ldC) {
         run.push_back(s);
         last = cur;
         continue;
@@ -635,7 +636,7 @@ static bool sweep_match(const Plan& P, Exec::SweepDesc* d) {
   if (best.size() < 2) return false;
   d->on = true; d->steps = best;
   d->ldIn = best_first.ldA; d->ldOut = best_last.ldC; d->ldWl = best_first.ldWl; d->ldWp = best_first.ldWp; d->ldX = best_first.ldX;
-  d->J = (int)(best_first.M / SWR);
+  d->J = (int)((best_first.M + SWR - 1) / SWR); d->M = (int)best_first.M; d->D = best_first.D; d->Pd = best_first.Pd;
   return true;
 }
 
@@ -686,7 +687,7 @@ static int exec_launch_steps(Exec* E) {
         const Step& f0 = P.steps[sd.steps.front()];
         SweepArgs w{};
         w.ptrs = E->d_ptrs; w.n_tensors = E->n_tensors; w.site_ids = E->d_sweep_ids;
-        w.idIn = f0.lhs; w.idOut = st.out; w.S = S; w.J = sd.J;
+        w.idIn = f0.lhs; w.idOut = st.out; w.S = S; w.J = sd.J; w.M = sd.M;
         w.ldIn = sd.ldIn; w.ldOut = sd.ldOut; w.ldWl = sd.ldWl; w.ldWp = sd.ldWp; w.ldX = sd.ldX;
         w.partIn = nullptr; w.PIn = 0; w.strideIn = 0; w.numelIn = 1.0;
         if (f0.lhs >= P.n_inputs && P.stabilize && P.steps[P.tensors[f0.lhs].producer].kernel != CTN_KERNEL_FUSED) {
@@ -697,7 +698,7 @@ static int exec_launch_steps(Exec* E) {
         }
         w.min_norm = P.min_norm;
         w.rec_a = E->d_sweep_a; w.rec_s = E->d_sweep_s; w.dbg = nullptr;
-        E->launched_tile[s] = (SWR << 16) | (SWD * SWP);   // 16 rows x all 1024 columns per workgroup, every site
+        E->launched_tile[s] = (SWR << 16) | (sd.D * sd.Pd);   // 16 rows x all columns (1024 at bond 256, d = 4) per workgroup, every site
         if (E->sw.stamps && (E->sw.stamp_step < 0 || E->sw.stamp_step == s)) {
           const size_t need = (size_t)sd.J * R;
           if (E->dbg_tiles < need) {
@@ -708,14 +709,26 @@ static int exec_launch_steps(Exec* E) {
           w.dbg = E->d_dbg;
           HIPCHECK(hipMemsetAsync(E->d_dbg, 0, E->dbg_tiles * 64, E->stream));
         }
-        hipLaunchKernelGGL(k_sweep_f32, dim3((unsigned)sd.J, (unsigned)R), dim3(512), 0, E->stream, w);
+        {
+          const dim3 gs((unsigned)sd.J, (unsigned)R);
+#define CTN_SWEEP_LAUNCH(DD)                                                                                   \
+          do {                                                                                                 \
+            if (sd.Pd == 4) hipLaunchKernelGGL((k_sweep_f32<DD, 4>), gs, dim3(DD == 64 ? 256 : 512), 0, E->stream, w);  \
+            else hipLaunchKernelGGL((k_sweep_f32<DD, 2>), gs, dim3(DD == 64 ? 256 : 512), 0, E->stream, w);            \
+          } while (0)
+          if (sd.D == 64) CTN_SWEEP_LAUNCH(64);
+          else if (sd.D == 128) CTN_SWEEP_LAUNCH(128);
+          else if (sd.D == 256) CTN_SWEEP_LAUNCH(256);
+          else CTN_SWEEP_LAUNCH(512);
+#undef CTN_SWEEP_LAUNCH
+        }
         const double numel = (double)P.tensors[st.out].numel;
         hipLaunchKernelGGL(k_sweep_logs, dim3((unsigned)S, (unsigned)R), dim3(256), 0, E->stream, (const double*)E->d_sweep_a,
                            (const float*)E->d_sweep_s, S, sd.J, E->d_sweep_la, E->d_sweep_ls);
         hipLaunchKernelGGL(k_sweep_z, dim3((unsigned)S, (unsigned)R), dim3(256), 0, E->stream, (const double*)E->d_sweep_la,
                            (const double*)E->d_sweep_ls, S, sd.J, numel, E->d_sweep_z);
         SweepFinish f{};
-        f.ptrs = E->d_ptrs; f.n_tensors = E->n_tensors; f.idOut = st.out; f.S = S; f.J = sd.J; f.R = R;
+        f.ptrs = E->d_ptrs; f.n_tensors = E->n_tensors; f.idOut = st.out; f.S = S; f.J = sd.J; f.R = R; f.D = sd.D; f.M = sd.M;
         f.ldOut = sd.ldOut; f.Z = E->d_sweep_z; f.ls = E->d_sweep_ls; f.part_off = E->d_sweep_off;
         f.part_slots = E->d_sweep_slots; f.partials = E->d_partials; f.numel = numel;
         f.min_norm = P.stabilize ? P.min_norm : INFINITY;
@@ -1474,7 +1487,9 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   // a sweep: at least half a chip of row blocks, or CTN_SWEEP=1
   if (!P.chain && E.sw.sweep != 0 && P.stabilize) {
     Exec::SweepDesc sd;
-    if (sweep_match(P, &sd) && (int)sd.steps.size() <= kSweepMaxSites && (E.sw.sweep == 1 || (sd.steps.size() >= 4 && (int64_t)sd.J * replicas * 2 >= E.n_cu))) {
+    // (bonds up to 128: the per-site launches are a few microseconds of latency each whatever the batch - always)
+    if (sweep_match(P, &sd) && (int)sd.steps.size() <= kSweepMaxSites &&
+        (E.sw.sweep == 1 || (sd.steps.size() >= 4 && (sd.D <= 128 || (int64_t)sd.J * replicas * 2 >= E.n_cu)))) {
       E.sweep = sd;
       const int S = (int)sd.steps.size();
       E.sweep_role.assign(P.n_steps, 0);

@@ -42,15 +42,15 @@ namespace ctn {
 // block's own scale - to the one scale the reference's stored tensor has.  Same numbers as the per-site launches up
 // to rounding; four launches instead of one per site.
 //
-// Conditions (engine.hip, sweep_match): fp32, |l| = |r| = 256, |p| = 4, rows a multiple of 16, W_s and x_s network
-// inputs with r and p unit-stride, E row-major.
+// Conditions (engine.hip, sweep_match): fp32, |l| = |r| = 64, 128, 256 or 512, |p| = 2 or 4, W_s and x_s network inputs
+// with r and p unit-stride, E row-major.  (The description above is the bond-256, d = 4 instance.)
 // ---------------------------------------------------------------------------
 struct SweepArgs {
   void* const* ptrs;         // [R][n_tensors]
   int32_t n_tensors;
   const int32_t* site_ids;   // [S][2]: tensor ids of (W_s, x_s)
   int32_t idIn, idOut;       // the chain's input E [b][l] and its output E' [b][r]
-  int32_t S, J;              // sites, row blocks (rows / 16)
+  int32_t S, J, M;           // sites, row blocks (ceil(rows / 16)), rows
   int64_t ldIn, ldOut;       // row strides of input and output (elements)
   int64_t ldWl, ldWp;        // W_s[l][p][r]: strides of l and p (r unit-stride)
   int64_t ldX;               // x_s[b][p]: row stride (p unit-stride)
@@ -62,26 +62,36 @@ struct SweepArgs {
   unsigned long long* dbg;   // CTN_STAMPS builds only
 };
 
-constexpr int SWD = 256, SWP = 4, SWR = 16, SWLD = SWD + 4;   // (row stride 260: the 16-byte reads of 16 rows spread over the banks)
+constexpr int SWR = 16;     // inputs per workgroup
 constexpr int SWQ = 4;      // k-steps of W in flight per wave (one loop body; 8 measured: the same - the CU's own load path is the limit)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) char* sw_gptr;   // global memory, said so: plain global_load / store
 typedef __attribute__((address_space(1))) float* sw_gout;
 
-__global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
-  __shared__ __attribute__((aligned(16))) float img[2][SWR * SWLD];
-  __shared__ __attribute__((aligned(16))) float xch[8 * 2 * 64 * 4];   // the halves' hand-over: 2 x 16 bytes per lane
-  __shared__ double red[8];
+// <D, P>: bond dimension (|l| = |r|: 64, 128, 256 or 512) and physical dimension (2 or 4).  Waves: D / 64 ranges of 64
+// values of r x NL parts of l (8 waves; 4 for D = 64): D = 256 as described above (4 x 2), D = 512 8 x 1 (no hand-over),
+// D = 128 2 x 4, D = 64 1 x 4.  The image rows are D + 4 floats apart (the 16-byte reads of 16 rows spread over the banks).
+template <int D, int P>
+__global__ __launch_bounds__(D == 64 ? 256 : 512, 1) void k_sweep_f32(SweepArgs a) {
+  constexpr int NWV = D == 64 ? 4 : 8, NT = 64 * NWV;
+  constexpr int NR = D / 64, NL = NWV / NR;   // ranges of r, parts of l
+  constexpr int LW = D / NL, NG = LW / 16;    // values of l per wave; its groups of 16 per site
+  constexpr int EK = 4 / NL;                  // of the four e (16-byte pieces of a lane's 16 values of r), a wave finishes EK
+  constexpr int LD = D + 4;
+  static_assert((D == 64 || D == 128 || D == 256 || D == 512) && (P == 2 || P == 4) && NG >= 1 && (NG & (NG - 1)) == 0, "shape");
+  __shared__ __attribute__((aligned(16))) float img[2][SWR * LD];
+  __shared__ __attribute__((aligned(16))) float xch[NL > 1 ? NWV * 4 * 64 * 4 : 4];   // the parts' hand-over: 4 x 16 bytes per lane
+  __shared__ double red[NWV];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int w4 = w & 3, kh = w >> 2;
+  const int w4 = w % NR, kh = w / NR;
   const int i16 = lane & 15, kg = lane >> 4;
   const int j = blockIdx.x, r = blockIdx.y;
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const size_t rec0 = (size_t)r * a.S * a.J + j;
-  const int srow = tid >> 5, scol = (tid & 31) * 8;   // a thread's share of a 16 x 256 image: 8 consecutive floats
+  const int rows = min(SWR, a.M - SWR * j);   // the last block of a batch that is not a multiple of 16: its other rows stay zero
 
   // the chain's input, normalised by its producer's mean (the lazy rescale: reference einsum.py:387 on the step before)
   {
@@ -98,39 +108,37 @@ __global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
     const float nI = (float)pv;
     const float inv = (a.partIn && nI > (float)a.min_norm) ? 1.0f / (nI / (float)a.numelIn) : 1.0f;
     const float* __restrict__ Ein = (const float*)tp[a.idIn] + (int64_t)(SWR * j) * a.ldIn;
-    const float4 v0 = *reinterpret_cast<const float4*>(Ein + (int64_t)srow * a.ldIn + scol);
-    const float4 v1 = *reinterpret_cast<const float4*>(Ein + (int64_t)srow * a.ldIn + scol + 4);
-    float* d = &img[0][srow * SWLD + scol];
-    *reinterpret_cast<float4*>(d) = make_float4(v0.x * inv, v0.y * inv, v0.z * inv, v0.w * inv);
-    *reinterpret_cast<float4*>(d + 4) = make_float4(v1.x * inv, v1.y * inv, v1.z * inv, v1.w * inv);
+    for (int i = tid; i < SWR * D / 4; i += NT) {
+      const int row = i / (D / 4), c4 = i - row * (D / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < rows) v = *reinterpret_cast<const float4*>(Ein + (int64_t)row * a.ldIn + 4 * c4);
+      *reinterpret_cast<float4*>(&img[0][row * LD + 4 * c4]) = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    }
   }
 
-  // a lane's own offsets into a core (bytes): row 4 kg of a group of its wave's half of l, its four columns r of every p
-  uint32_t voff[SWP];
+  // a lane's own offsets into a core (bytes): row 4 kg of a group of its wave's part of l, its four columns r of every p
+  uint32_t voff[P];
 #pragma unroll
-  for (int p = 0; p < SWP; ++p)
-    voff[p] = (uint32_t)(((int64_t)(SWD / 2 * kh + 4 * kg) * a.ldWl + (int64_t)p * a.ldWp + 64 * w4 + 4 * i16) * 4);
+  for (int p = 0; p < P; ++p)
+    voff[p] = (uint32_t)(((int64_t)(LW * kh + 4 * kg) * a.ldWl + (int64_t)p * a.ldWp + 64 * w4 + 4 * i16) * 4);
   const int64_t stepW = a.ldWl * 4;           // next k-step of a group (bytes)
 
   sw_gptr Wcur = (sw_gptr)tp[a.site_ids[0]];
   sw_gptr Xcur = (sw_gptr)tp[a.site_ids[1]];
-  f32x4 wq[SWQ][SWP];
+  f32x4 wq[SWQ][P];
   // the groups of a site are walked from a block-dependent start (CUs of one XCD then ask its L2 for different lines)
-  const int rot = (j >> 3) & 7;               // (-3 % of the time against every block starting at group 0)
+  const int rot = (j >> 3) & (NG - 1);        // (-3 % of the time against every block starting at group 0)
   sw_gptr wpf = Wcur + (int64_t)(16 * rot) * stepW;   // the group being requested (wave-uniform)
-  auto wrequest = [&](f32x4 (&dst)[SWP], int t) {
+  auto wrequest = [&](f32x4 (&dst)[P], int t) {
 #pragma unroll
-    for (int p = 0; p < SWP; ++p) dst[p] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(wpf + (int64_t)t * stepW + voff[p]);
+    for (int p = 0; p < P; ++p) dst[p] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(wpf + (int64_t)t * stepW + voff[p]);
   };
 #pragma unroll
-  for (int u = 0; u < SWQ; ++u) {
-    if (u == 4) wpf = Wcur + (int64_t)(16 * ((rot + 1) & 7)) * stepW;
-    wrequest(wq[u], u & 3);
-  }
+  for (int u = 0; u < SWQ; ++u) wrequest(wq[u], u);
 
-  f32x4 acc[SWP][4];
+  f32x4 acc[P][4];
 #pragma unroll
-  for (int p = 0; p < SWP; ++p)
+  for (int p = 0; p < P; ++p)
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -144,113 +152,120 @@ __global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
   float inv_s = 1.0f;
   int cur = 0;
   sw_gptr Wnext = Wcur, Xnext = Xcur;
-  constexpr int NG = SWD / 2 / 16;            // groups of 16 values of l per wave and site: its half of l
   for (int s = 0; s < a.S; ++s) {
     const bool last = s + 1 == a.S;
     // next site's tensors (the last site re-requests its own first k-steps: in bounds, never used)
     const int sn = last ? s : s + 1;
     Wnext = (sw_gptr)tp[a.site_ids[2 * sn]];
     Xnext = (sw_gptr)tp[a.site_ids[2 * sn + 1]];
-    const f32x4 xr = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(Xcur + (int64_t)(SWR * j + i16) * a.ldX * 4);
-    const float* erow = &img[cur][i16 * SWLD + SWD / 2 * kh + 4 * kg];
-    float4 ef = *reinterpret_cast<const float4*>(erow + 16 * rot);
-    constexpr int GB = SWQ / 4;                        // groups per loop body = groups requested ahead
-#pragma unroll 1
-    for (int G0 = 0; G0 < NG; G0 += GB) {
-#pragma unroll
-      for (int gb = 0; gb < GB; ++gb) {
-        const int G = G0 + gb;
-        const int gn = (G + 1 + rot) & (NG - 1);       // the next group: its B operands
-        const int gq = (G + GB + rot) & (NG - 1);      // the group GB ahead: its cores' requests (past the last: the next site's)
-        wpf = (G + GB >= NG ? Wnext : Wcur) + (int64_t)(16 * gq) * stepW;
-        const float4 en = *reinterpret_cast<const float4*>(erow + 16 * gn);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float ev = t == 0 ? ef.x : t == 1 ? ef.y : t == 2 ? ef.z : ef.w;
-#pragma unroll
-          for (int p = 0; p < SWP; ++p)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              // (LAB_NOTES R3.6, cycles per site of the slower wave of a SIMD: these MFMAs alone, on a queue that is
-              // never refilled, 34 k - the ideal is 32.8 k; the stream alone, one FMA here, ~36 k; together 44 k, on 128
-              // CUs as on 256: a CU's own load path, not the L2, sets the pace)
-              acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[4 * gb + t][p][c], ev, acc[p][c], 0, 0, 0);
-            }
-          wrequest(wq[4 * gb + t], t);
-          if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the next group's B operands first
-#pragma unroll
-          for (int p = 0; p < SWP; ++p) {      // a request after every four MFMAs (all four behind the sixteen: +5 % time)
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          }
-        }
-        ef = en;
+    float xr[P];                               // the inputs' weights of this site (rows beyond the batch: 0)
+    {
+      const int row = min(SWR * j + i16, a.M - 1);
+      sw_gptr xp = Xcur + (int64_t)row * a.ldX * 4;
+      if constexpr (P == 4) {
+        const f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(xp);
+        xr[0] = v.x; xr[1] = v.y; xr[2] = v.z; xr[3] = v.w;
+      } else {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 v = *reinterpret_cast<const __attribute__((address_space(1))) f32x2*>(xp);
+        xr[0] = v.x; xr[1] = v.y;
       }
+    }
+    const float* erow = &img[cur][i16 * LD + LW * kh + 4 * kg];
+    float4 ef = *reinterpret_cast<const float4*>(erow + 16 * rot);
+#pragma unroll 1
+    for (int G = 0; G < NG; ++G) {
+      const int gn = (G + 1 + rot) & (NG - 1);         // the next group: its B operands, its cores' requests
+      wpf = (G == NG - 1 ? Wnext : Wcur) + (int64_t)(16 * gn) * stepW;   // (after the last group: the next site's first)
+      const float4 en = *reinterpret_cast<const float4*>(erow + 16 * gn);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float ev = t == 0 ? ef.x : t == 1 ? ef.y : t == 2 ? ef.z : ef.w;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            // (LAB_NOTES R3.6, cycles per site of the slower wave of a SIMD at D = 256, P = 4: these MFMAs alone, on a queue
+            // that is never refilled, 34 k - the ideal is 32.8 k; the stream alone, one FMA here, ~36 k; together 44 k, on
+            // 128 CUs as on 256: a CU's own load path, not the L2, sets the pace)
+            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t][p][c], ev, acc[p][c], 0, 0, 0);
+          }
+        wrequest(wq[t], t);
+        if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the next group's B operands first
+#pragma unroll
+        for (int p = 0; p < P; ++p) {        // a request after every four MFMAs (all of them behind the k-step's MFMAs: +5 % time)
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+      ef = en;
     }
 #ifdef CTN_STAMPS
     { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); st_loop += t1 - st0; st0 = t1; }
 #endif
-    // ---- the site's epilogue: E'[b][r] = sum_p x[b][p] C[b][(p, r)], this wave's half of the sum over l; a lane has
-    // r = 64 w4 + 16 kg + 4 e + c.  The two halves meet through LDS: each hands the other one two of its four e and
-    // finishes the other two (first half + second half).  The state in LDS is the un-rescaled one: its scale goes into
-    // the weights - four multiplications per site.  (ds_add_f32 into a zeroed image instead: 12 k cycles per site.)
-    const float xs[4] = {xr.x * inv_s, xr.y * inv_s, xr.z * inv_s, xr.w * inv_s};
+    // ---- the site's epilogue: E'[b][r] = sum_p x[b][p] C[b][(p, r)], this wave's part of the sum over l; a lane has
+    // r = 64 w4 + 16 kg + 4 e + c.  The NL parts meet through LDS: every wave leaves its four 16-byte pieces e there and
+    // finishes EK = 4 / NL of them - the sum over the parts in their order.  The state in LDS is the un-rescaled one: its
+    // scale goes into the weights - P multiplications per site.  (ds_add_f32 into a zeroed image instead: 12 k cycles.)
+    float xs[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) xs[p] = (SWR * j + i16 < a.M ? xr[p] : 0.f) * inv_s;
     const int nxt = cur ^ 1;
-    // o[e][c], e = 0..3: this wave keeps e = 2 kh, 2 kh + 1 ("mine") and hands over the other two ("give")
-    float mine[2][4], give[2][4];
+    float o[4][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float v = xs[0] * acc[0][c][e];
-        v = fmaf(xs[1], acc[1][c][e], v);
-        v = fmaf(xs[2], acc[2][c][e], v);
-        v = fmaf(xs[3], acc[3][c][e], v);
-        if (e < 2) { mine[e][c] = v; } else { give[e - 2][c] = v; }
+#pragma unroll
+        for (int p = 1; p < P; ++p) v = fmaf(xs[p], acc[p][c][e], v);
+        o[e][c] = v;
       }
-    if (kh) {                                  // (wave-uniform: the second half keeps e = 2, 3)
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { const float tsw = mine[e][c]; mine[e][c] = give[e][c]; give[e][c] = tsw; }
-    }
-#pragma unroll
-    for (int p = 0; p < SWP; ++p)
+    for (int p = 0; p < P; ++p)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[p][c][e] = 0.f;
-    {
-      float4* gv = reinterpret_cast<float4*>(xch) + (w * 2) * 64 + lane;
-      gv[0] = make_float4(give[0][0], give[0][1], give[0][2], give[0][3]);
-      gv[64] = make_float4(give[1][0], give[1][1], give[1][2], give[1][3]);
+    if constexpr (NL > 1) {
+      float4* gv = reinterpret_cast<float4*>(xch) + (w * 4) * 64 + lane;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gv[e * 64] = make_float4(o[e][0], o[e][1], o[e][2], o[e][3]);
+      // two barriers per site; only the LDS traffic is waited for - the cores requested ahead stay in flight
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // two barriers per site; only the LDS traffic is waited for - the cores requested ahead stay in flight
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
     {
-      const float4* take = reinterpret_cast<const float4*>(xch) + ((w ^ 4) * 2) * 64 + lane;
-      const float4 t0 = take[0], t1 = take[64];
-      const float4 m0 = make_float4(mine[0][0], mine[0][1], mine[0][2], mine[0][3]);
-      const float4 m1 = make_float4(mine[1][0], mine[1][1], mine[1][2], mine[1][3]);
-      const float4 f0 = make_float4(m0.x + t0.x, m0.y + t0.y, m0.z + t0.z, m0.w + t0.w);
-      const float4 f1 = make_float4(m1.x + t1.x, m1.y + t1.y, m1.z + t1.z, m1.w + t1.w);
-      const int col = 64 * w4 + 16 * kg + 8 * kh;          // e = 2 kh, 2 kh + 1: eight consecutive r
-      if (last) {     // the last site's rows leave with this block's own scale (k_sweep_finish brings them to the common one)
-        sw_gout og = (sw_gout)tp[a.idOut] + (int64_t)(SWR * j + i16) * a.ldOut + col;
-        *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(og) = f32x4{f0.x, f0.y, f0.z, f0.w};
-        *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(og + 4) = f32x4{f1.x, f1.y, f1.z, f1.w};
-      } else {
-        float* d = &img[nxt][i16 * SWLD + col];
-        *reinterpret_cast<float4*>(d) = f0;
-        *reinterpret_cast<float4*>(d + 4) = f1;
+      float asum = 0.f;
+#pragma unroll
+      for (int q = 0; q < EK; ++q) {
+        const int e = EK * kh + q;             // (wave-uniform)
+        float4 f;
+        if constexpr (NL > 1) {
+          f = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int part = 0; part < NL; ++part) {
+            const float4 tk = (reinterpret_cast<const float4*>(xch) + ((part * NR + w4) * 4 + e) * 64)[lane];
+            f = part == 0 ? tk : make_float4(f.x + tk.x, f.y + tk.y, f.z + tk.z, f.w + tk.w);
+          }
+        } else {
+          f = make_float4(o[q][0], o[q][1], o[q][2], o[q][3]);
+        }
+        const int col = 64 * w4 + 16 * kg + 4 * e;
+        if (last) {   // the last site's rows leave with this block's own scale (k_sweep_finish brings them to the common one)
+          if (i16 < rows) {
+            sw_gout og = (sw_gout)tp[a.idOut] + (int64_t)(SWR * j + i16) * a.ldOut + col;
+            *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(og) = f32x4{f.x, f.y, f.z, f.w};
+          }
+        } else {
+          *reinterpret_cast<float4*>(&img[nxt][i16 * LD + col]) = f;
+        }
+        asum += (fabsf(f.x) + fabsf(f.y)) + (fabsf(f.z) + fabsf(f.w));
       }
-      const float asum = ((fabsf(f0.x) + fabsf(f0.y)) + (fabsf(f0.z) + fabsf(f0.w))) +
-                         ((fabsf(f1.x) + fabsf(f1.y)) + (fabsf(f1.z) + fabsf(f1.w)));
       double part = (double)asum;
 #pragma unroll
       for (int of = 32; of > 0; of >>= 1) part += __shfl_xor(part, of, 64);
@@ -264,8 +279,8 @@ __global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     double tot = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) tot += red[i];
-    const float sc = (!last && tot > 1e-30) ? (float)(tot / (double)(SWR * SWD)) : 1.0f;
+    for (int i = 0; i < NWV; ++i) tot += red[i];
+    const float sc = (!last && tot > 1e-30) ? (float)(tot / (double)(SWR * D)) : 1.0f;
     inv_s = 1.0f / sc;
     if (tid == 0) {
       a.rec_a[rec0 + (size_t)s * a.J] = tot;
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep_f32(SweepArgs a) {
 #endif
   }
 #ifdef CTN_STAMPS
-  if (a.dbg && (tid == 0 || tid == 448)) {
+  if (a.dbg && (tid == 0 || tid == NT - 64)) {
     unsigned long long* d = a.dbg + ((size_t)r * a.J + j) * 8 + (tid ? 4 : 0);
     d[0] = st_begin; d[1] = st0; d[2] = st_loop; d[3] = st_epi;
   }
@@ -340,7 +355,7 @@ __global__ __launch_bounds__(256) void k_sweep_z(const double* __restrict__ la, 
 // common scale.  grid (J, R), 256 threads.
 struct SweepFinish {
   void* const* ptrs;
-  int32_t n_tensors, idOut, S, J, R;
+  int32_t n_tensors, idOut, S, J, R, D, M;   // D: bond dimension; M: rows (the last block may hold fewer than 16)
   int64_t ldOut;
   const double* Z;           // [R][S]
   const double* ls;          // [R][S][J] log of the scales the blocks applied
@@ -384,8 +399,9 @@ __global__ __launch_bounds__(256) void k_sweep_finish(SweepFinish f) {
   }
   const float fac = (float)exp(fac_log);
   float* out = (float*)f.ptrs[(size_t)r * f.n_tensors + f.idOut] + (int64_t)(SWR * j) * f.ldOut;
-  for (int i = threadIdx.x; i < SWR * SWD / 4; i += 256) {
-    const int row = i / (SWD / 4), c4 = i - row * (SWD / 4);
+  const int rows = min(SWR, f.M - SWR * j), q4 = f.D / 4;
+  for (int i = threadIdx.x; i < rows * q4; i += 256) {
+    const int row = i / q4, c4 = i - row * q4;
     float4* p = reinterpret_cast<float4*>(out + (int64_t)row * f.ldOut) + c4;
     float4 v = *p;
     v.x *= fac; v.y *= fac; v.z *= fac; v.w *= fac;

@@ -1178,10 +1178,21 @@ def test_zipper_pairs_in_one_launch_match_the_two_step_path(sites, phys, replica
 
 
 # ---- a batched MPS as ONE launch (k_sweep_f32): 16 inputs per workgroup walk every site of the chain --------------------
-@pytest.mark.parametrize("sites,batch,replicas,spread", [(6, 64, 1, 1.0), (9, 160, 2, 1.0), (7, 80, 1, 1e6)])
-def test_sweep_of_a_batched_mps_matches_the_per_site_launches(sites, batch, replicas, spread, monkeypatch):
-    """The reference's ML workload (README Fig. 1d; BASELINE config 3b) at bond 256, physical dimension 4: with
-    CTN_SWEEP=1 the interior sites - one epilogue-summed GEMM step each - run as ONE k_sweep_f32 launch in which
+@pytest.mark.parametrize("sites,batch,replicas,spread,bond,phys", [
+    (6, 64, 1, 1.0, 256, 4), (9, 160, 2, 1.0, 256, 4), (7, 80, 1, 1e6, 256, 4),
+    (7, 144, 1, 1.0, 256, 2),        # physical dimension 2
+    (8, 272, 2, 1e4, 128, 4),        # bond 128: 2 ranges of r x 4 parts of l
+    (9, 528, 1, 1.0, 64, 4),         # bond 64: a 4-wave workgroup, one group of l per wave
+    (12, 1040, 1, 1.0, 64, 2),
+    (5, 64, 1, 1.0, 512, 4),         # bond 512: 8 ranges of r, no hand-over
+    (6, 88, 1, 1.0, 512, 2),         # ... 88 inputs: the last block holds 8
+    (7, 264, 1, 1.0, 128, 2),        # 264 inputs: the last block holds 8
+    (6, 100, 2, 1e3, 256, 4),        # 100 inputs: the last block holds 4
+])
+def test_sweep_of_a_batched_mps_matches_the_per_site_launches(sites, batch, replicas, spread, bond, phys, monkeypatch):
+    """The reference's ML workload (README Fig. 1d; BASELINE config 3b) at bonds 64 ... 512, physical dimension 2 and 4,
+    batches that are not multiples of 16: with
+    CTN_SWEEP=1 the interior sites - one epilogue-summed GEMM step each - run as ONE k_sweep_f32<bond, phys> launch in which
     every block of 16 inputs rescales by its OWN mean; k_sweep_z / k_sweep_finish reconstruct the reference's
     per-step rescale factors (mean over ALL inputs, einsum.py:97-106).  Against the per-site launches (CTN_SWEEP=0):
     result, log-scale and EVERY step's rescale factor; against the oracle; replicas; blocks of very different
@@ -1191,7 +1202,6 @@ def test_sweep_of_a_batched_mps_matches_the_per_site_launches(sites, batch, repl
     from oracle import cpu_ref
     from tests import networks as nets
 
-    bond, phys = 256, 4
     tn, inputs = nets.batched_mps(TN, sites, bond, phys, batch, dtype=np.float32, seed=4)
     path = ssa_to_linear(nets.batched_mps_path(sites), 2 * sites)
     ops0 = [np.asarray(o) for o in E.make_arg_packer(tn)(tn.params, inputs)]
@@ -1199,7 +1209,7 @@ def test_sweep_of_a_batched_mps_matches_the_per_site_launches(sites, batch, repl
     rng = np.random.default_rng(7)
     sets = []
     for r in range(replicas):
-        ops = [(rng.standard_normal(sh) * (0.25 if len(sh) == 2 and sh[0] == batch else 1.0 / 16.0)).astype(np.float32) for sh in shapes]
+        ops = [(rng.standard_normal(sh) * (0.25 if len(sh) == 2 and sh[0] == batch else 1.0 / np.sqrt(bond))).astype(np.float32) for sh in shapes]
         if spread != 1.0:
             for o in ops:
                 if o.shape == (batch, phys):
@@ -1216,9 +1226,9 @@ def test_sweep_of_a_batched_mps_matches_the_per_site_launches(sites, batch, repl
         res[mode] = (t, c, bc.executor.step_tiles(), bc.executor.fetch()[1])
         bc.executor.close()
     tiles = res["1"][2]
-    whole = [s for s, tl in enumerate(tiles) if tl == (16, 1024)]
+    whole = [s for s, tl in enumerate(tiles) if tl == (16, bond * phys)]
     assert len(whole) == 1 and sum(tl == (1, 1) for tl in tiles) >= sites - 3, tiles
-    assert not any(tl == (16, 1024) for tl in res["0"][2])
+    assert not any(tl == (16, bond * phys) for tl in res["0"][2])
     for r in range(replicas):
         r0, r1 = np.asarray(res["0"][3][r]), np.asarray(res["1"][3][r])
         assert np.array_equal(r0 == 0.0, r1 == 0.0)                               # the same steps are rescaled

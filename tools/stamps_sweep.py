@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Development tool: per-workgroup cycle stamps of the k_sweep_f32 launch of the batched MPS (BASELINE config 3b).
-Needs a `make STAMPS=1 EXP=n` library: CTN_LIB_PATH=contractn_amd/lib/libctn_hip_expn.so python tools/stamps_sweep.py [B] [sites]"""
+Needs a `make STAMPS=1 EXP=n` library: CTN_LIB_PATH=contractn_amd/lib/libctn_hip_expn.so python tools/stamps_sweep.py [B] [sites]
+Timing only (any library): python tools/stamps_sweep.py child B sites [bond] [phys]   (CTN_SWEEP=0: the per-site launches)"""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,13 +12,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from contractn_amd.einsum import BatchedContraction
     from contractn_amd.paths import ssa_to_linear
     from tests import networks as nets
-    B, n_sites, bond, phys = int(sys.argv[2]), int(sys.argv[3]), 256, 4
+    B, n_sites = int(sys.argv[2]), int(sys.argv[3])
+    bond = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+    phys = int(sys.argv[5]) if len(sys.argv) > 5 else 4
     tn, inputs = nets.batched_mps(TN, n_sites, bond, phys, 16, dtype=np.float32, seed=4)
     shapes = [p.shape for p in tn.params] + [(B, phys)] * n_sites
     path = ssa_to_linear(nets.batched_mps_path(n_sites), 2 * n_sites)
     bc = BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=1)
     gen = torch.Generator(device="cuda"); gen.manual_seed(0)
-    ops = [torch.randn(s, generator=gen, device="cuda") / 4.0 for s in shapes]
+    ops = [torch.randn(s, generator=gen, device="cuda") / (4.0 if len(s) == 2 and s[0] == B else bond ** 0.5) for s in shapes]
     out = torch.zeros((1,) + tuple(bc.plan.out_shape), device="cuda")
     if os.environ.get("SWEEP_ALIAS"):     # every interior core the same buffer: the stream comes out of L2 for sure
         for i in range(2, n_sites - 1):
@@ -33,7 +36,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     bc.executor.synchronize()
     print("ms per pass", (time.perf_counter() - t0) * 100.0)
     tiles = bc.executor.step_tiles()
-    print([s for s, t in enumerate(tiles) if t == (16, 1024)])
+    print([s for s, t in enumerate(tiles) if t[0] == 16 and t[1] >= 128])
 else:
     B = sys.argv[1] if len(sys.argv) > 1 else "4096"
     sites = sys.argv[2] if len(sys.argv) > 2 else "100"
