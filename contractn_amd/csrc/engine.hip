@@ -60,6 +60,7 @@ struct DevSwitches {
   int lat = -1;          // CTN_LAT: 0 never use the one-launch latency form (k_mfma_f32_lat), 1 whenever the shape allows (tests)
   int hform = -1;        // CTN_H: 0 never use the one-tile-per-CU form (k_mfma_f32_h), 1 whenever the shape allows (tests)
   int sweep = -1;        // CTN_SWEEP: 0 never walk a chain of epilogue-summed steps in one launch (k_sweep_f32), 1 whenever one matches (tests)
+  int dot_tr = 1;        // CTN_DOT_TR=0: full dots against a transposed tensor stay on k_dot_split's 4-byte gathers
   int zip = -1;          // CTN_ZIP: 0 never fuse a zipper's two GEMM steps into one launch (k_zip_f32), 1 whenever the pair matches (tests)
   bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
   const char* stamps = nullptr;  // CTN_DEBUG_STAMPS=<file> (make STAMPS=1 builds): dump in-kernel cycle stamps
@@ -77,6 +78,7 @@ static DevSwitches read_dev_switches() {
   d.lat = num("CTN_LAT", -1);
   d.hform = num("CTN_H", -1);
   d.zip = num("CTN_ZIP", -1);
+  d.dot_tr = num("CTN_DOT_TR", 1);
   d.sweep = num("CTN_SWEEP", -1);
   d.lat64_min_k = num("CTN_LAT64_MIN_K", 512);
   d.splitk_fill_long = num("CTN_SPLITK_FILL_LONG", 2);
@@ -151,6 +153,9 @@ struct Exec {
   double* d_sweep_z = nullptr;         // [R][S]
   double* d_sweep_la = nullptr;        // [R][S][J] logs of d_sweep_a / d_sweep_s
   double* d_sweep_ls = nullptr;
+  // full dots of a tensor with a transposed one (k_dot_tr), found on the plan's tables when the executor is created
+  struct DotTr { bool on = false; int Ka = 0, Kb = 0, x_is_a = 1; int64_t ldY = 0; };
+  std::vector<DotTr> dot_tr;
   std::vector<int32_t> launched_tile;  // per step: (tile rows << 16 | tile columns) of the last enqueue's MFMA kernel, else 0
   char* d_ws = nullptr;
   int32_t* d_tables = nullptr;
@@ -640,6 +645,33 @@ static bool sweep_match(const Plan& P, Exec::SweepDesc* d) {
   return true;
 }
 
+// Is this split dot step the sum over k = (a, b) of X[a Kb + b] Y[b ldY + a] - one operand contiguous in k, the other
+// one its transpose (k_dot_tr)?  Checked on the plan's k tables.
+static bool dot_tr_match(const Plan& P, const Step& st, Exec::DotTr* d) {
+  if (st.kernel != CTN_KERNEL_DOT || st.K < 32768 || st.K >= (1LL << 31)) return false;
+  const int32_t* T = P.tables.data();
+  for (int x_is_a = 1; x_is_a >= 0; --x_is_a) {
+    const int32_t* kx = T + (x_is_a ? st.t.okA : st.t.okB);
+    const int32_t* ky = T + (x_is_a ? st.t.okB : st.t.okA);
+    bool contig = true;
+    for (int64_t k = 0; k < st.K && contig; ++k) contig = kx[k] == k;
+    if (!contig || ky[0] != 0) continue;
+    const int64_t ldY = ky[1];
+    if (ldY < 32) continue;
+    int64_t Kb = 0;
+    for (int64_t k = 1; k < st.K; ++k) if (ky[k] == 1) { Kb = k; break; }
+    if (Kb < 32 || st.K % Kb != 0) continue;
+    const int64_t Ka = st.K / Kb;
+    if (Ka % 32 != 0 || Kb % 32 != 0 || ldY < Ka) continue;
+    bool ok = true;
+    for (int64_t k = 0; k < st.K && ok; ++k) ok = ky[k] == (k % Kb) * ldY + k / Kb;
+    if (!ok) continue;
+    d->on = true; d->Ka = (int)Ka; d->Kb = (int)Kb; d->x_is_a = x_is_a; d->ldY = ldY;
+    return true;
+  }
+  return false;
+}
+
 static int exec_launch_steps(Exec* E) {
   const Plan& P = *E->plan;
   const int R = E->R;
@@ -1060,11 +1092,14 @@ static int exec_launch_steps(Exec* E) {
           sk.kchunk = (int32_t)(((st.K + S0 - 1) / S0 + 255) / 256 * 256);
           sk.S = (int32_t)((st.K + sk.kchunk - 1) / sk.kchunk);
           const dim3 g((unsigned)((int64_t)st.blocks * sk.S), R);
+          const Exec::DotTr dt = (int)E->dot_tr.size() == P.n_steps ? E->dot_tr[s] : Exec::DotTr();
           if (P.dtype == CTN_F32) {
-            hipLaunchKernelGGL(k_dot_split<float>, g, dim3(256), 0, E->stream, a, (float*)sk.slab, sk.numelC, sk.S, sk.kchunk);
+            if (dt.on) hipLaunchKernelGGL(k_dot_tr<float>, g, dim3(256), 0, E->stream, a, (float*)sk.slab, sk.numelC, sk.S, dt.Ka, dt.Kb, dt.ldY, dt.x_is_a);
+            else hipLaunchKernelGGL(k_dot_split<float>, g, dim3(256), 0, E->stream, a, (float*)sk.slab, sk.numelC, sk.S, sk.kchunk);
             launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
           } else {
-            hipLaunchKernelGGL(k_dot_split<double>, g, dim3(256), 0, E->stream, a, (double*)sk.slab, sk.numelC, sk.S, sk.kchunk);
+            if (dt.on) hipLaunchKernelGGL(k_dot_tr<double>, g, dim3(256), 0, E->stream, a, (double*)sk.slab, sk.numelC, sk.S, dt.Ka, dt.Kb, dt.ldY, dt.x_is_a);
+            else hipLaunchKernelGGL(k_dot_split<double>, g, dim3(256), 0, E->stream, a, (double*)sk.slab, sk.numelC, sk.S, sk.kchunk);
             launch_splitk_reduce<double>(E, E->step_partials[s], R, a, sk);
           }
           break;
@@ -1483,6 +1518,13 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     } else {
       E.zip.clear(); E.zip_skip.clear();
     }
+  }
+  // full dots against a transposed tensor
+  if (!P.chain && E.sw.dot_tr) {
+    E.dot_tr.assign(P.n_steps, Exec::DotTr());
+    bool any = false;
+    for (int s = 0; s < P.n_steps; ++s) any = dot_tr_match(P, P.steps[s], &E.dot_tr[s]) || any;
+    if (!any) E.dot_tr.clear();
   }
   // a sweep: at least half a chip of row blocks, or CTN_SWEEP=1
   if (!P.chain && E.sw.sweep != 0 && P.stabilize) {

@@ -402,6 +402,50 @@ __global__ __launch_bounds__(256) void k_dot_split(StepArgs a, T* __restrict__ s
     slab[((size_t)r * S + s) * numelC + a.obC[b] + a.omC[m] + a.onC[n]] = tot;
 }
 
+// k_dot_tr: a full dot product of two tensors one of which is stored TRANSPOSED relative to the other - the two boundary
+// halves of a sliced 2D grid closed by one 262144-long sum (`_tensordot` with every index contracted, reference
+// einsum.py:371): k = (a, b), X contiguous in k (offset a Kb + b), Y[b ldY + a].  k_dot_split gathers Y four bytes at a
+// time, every lane another cache line (0.8 TB/s); here a workgroup takes 32 x 32 tiles of (a, b): both operands are
+// read along their own unit-stride index - 128-byte rows - and Y's tile turns round in LDS.  grid (outputs x S, R);
+// split s takes tiles s, s + S, ...; the partial sums go through the split-K reduce pass like k_dot_split's.
+template <typename T>
+__global__ __launch_bounds__(256) void k_dot_tr(StepArgs a, T* __restrict__ slab, int64_t numelC, int S, int Ka, int Kb,
+                                                int64_t ldY, int x_is_a) {
+  __shared__ double red[4];
+  __shared__ T tile[32][33];
+  const int r = blockIdx.y;
+  void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
+  const int o = blockIdx.x / S, s = blockIdx.x - o * S;
+  const int n = o % a.N;
+  const int q = o / a.N;
+  const int m = q % a.M;
+  const int b = q / a.M;
+  const T* pa = (const T*)tp[a.idA] + a.obA[b] + a.omA[m];
+  const T* pb = (const T*)tp[a.idB] + a.obB[b] + a.onB[n];
+  const T* __restrict__ X = x_is_a ? pa : pb;       // contiguous in k
+  const T* __restrict__ Y = x_is_a ? pb : pa;       // transposed
+  const int j = threadIdx.x & 31, i0 = threadIdx.x >> 5;
+  const int tb = Kb / 32, tiles = (Ka / 32) * tb;
+  T acc = 0;
+  for (int t = s; t < tiles; t += S) {
+    const int a0 = (t / tb) * 32, b0 = (t % tb) * 32;
+    T x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 8 * u;
+      x[u] = X[(int64_t)(a0 + i) * Kb + b0 + j];
+      tile[i][j] = Y[(int64_t)(b0 + i) * ldY + a0 + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = fma(x[u], tile[j][i0 + 8 * u], acc);
+    __syncthreads();
+  }
+  const T tot = (T)block_sum((double)acc, red);
+  if (threadIdx.x == 0)
+    slab[((size_t)r * S + s) * numelC + a.obC[b] + a.omC[m] + a.onC[n]] = tot;
+}
+
 // Collapse more per-workgroup partials than a consumer wave adds (kMaxPartials) into one, in a fixed order;
 // the step's region then has a single slot per replica.
 __global__ __launch_bounds__(256) void k_collapse(const double* scratch, int blocks, double* part) {

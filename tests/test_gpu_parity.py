@@ -1292,3 +1292,36 @@ def test_sweep_steps_aside_in_eager_mode_and_survives_an_eager_repeat(monkeypatc
     lazy.executor.close(); eager.executor.close()
     monkeypatch.delenv("CTN_SWEEP")
     E.clear_caches()
+
+
+# ---- a full dot of a tensor with a transposed one (k_dot_tr) -----------------------------------------------------------------
+@pytest.mark.parametrize("einstr,shapes,dtype", [
+    ("ab,ba->", [(512, 512), (512, 512)], np.float32),           # the closing dot of a sliced 8 x 8 PEPS (D = 8)
+    ("ab,ba->", [(256, 1024), (1024, 256)], np.float32),
+    ("ab,ba->", [(1024, 64), (64, 1024)], np.float64),
+    ("xab,xba->x", [(3, 256, 256), (3, 256, 256)], np.float32),  # a batch (hyperedge) label: three outputs
+    ("abc,cab->", [(64, 32, 32), (32, 64, 32)], np.float32),     # k = (a, (b, c)) against ((c), (a, b)): NOT a plain transpose
+])
+def test_full_dot_against_a_transposed_tensor(einstr, shapes, dtype, monkeypatch):
+    """Both operands are read along their own unit-stride index and one tile turns round in LDS; against NumPy and against
+    the 4-byte gathers of k_dot_split (CTN_DOT_TR=0), two replicas, twice for bit-identity."""
+    rng = np.random.default_rng(23)
+    ops = [rng.standard_normal(s).astype(dtype) for s in shapes]
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops])
+    tol = 2e-4 if dtype == np.float32 else 1e-11
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CTN_DOT_TR", mode)
+        E.clear_caches()
+        bc = E.BatchedContraction(einstr, shapes, dtype, optimize=((0, 1),), replicas=2)
+        t, c = bc.run_host([ops, [2 * o for o in ops]])
+        t2, c2 = bc.run_host([ops, [2 * o for o in ops]])
+        assert np.array_equal(t, t2) and np.array_equal(c, c2)
+        for r, f in ((0, 1.0), (1, 4.0)):
+            got = np.asarray(t[r], dtype=np.float64) * np.exp(float(c[r]))
+            assert np.max(np.abs(got - f * ref)) <= tol * f * max(1.0, np.max(np.abs(ref)) * 10), (mode, r)
+        res[mode] = np.asarray(t[0], dtype=np.float64) * np.exp(float(c[0]))
+        bc.executor.close()
+    assert np.max(np.abs(res["0"] - res["1"])) <= tol * max(1.0, np.max(np.abs(ref)) * 10)
+    monkeypatch.delenv("CTN_DOT_TR")
+    E.clear_caches()
