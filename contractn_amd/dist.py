@@ -1492,6 +1492,13 @@ class StagedSlicedContraction:
                 self.root_members.append([where[v] for v in grp if tuple(v[i] for i in dep_idx[-1]) == e])
 
         self.tstream = torch.cuda.Stream(dev)
+        # Stages that do not feed each other (the quadrants of a 2D grid) are chains of small, latency-bound launches:
+        # each gets a stream of its own (four in rotation; the root keeps the main one) and events carry the tree's
+        # dependencies, so that one stage's launch latencies hide behind another's kernels.  Only when every stage is
+        # evaluated once per contraction (one group; the host loop over `outer` labels re-uses buffers between groups).
+        multi = n_stage > 2 and len(groups) == 1 and os.environ.get("CTN_STAGE_STREAMS", "1") != "0"
+        pool = [torch.cuda.Stream(dev) for _ in range(min(4, n_stage - 1))] if multi else []
+        self.stage_streams = [pool[k % len(pool)] if pool and k < n_stage - 1 else self.tstream for k in range(n_stage)]
         # inputs: sliced axes first (in slice_labels order), so a slice is one contiguous block at a pointer offset
         self.tensors, lead_labels, blocks = [], [], []
         for term, op in zip(terms, operands):
@@ -1567,7 +1574,7 @@ class StagedSlicedContraction:
             per = max(1, probe.workspace_bytes(2) - probe.workspace_bytes(1))
             R = int(max(1, min(max(len(x) for x in need[k]), workspace_budget // per)))
             bc = E.BatchedContraction(st_einsum, st_shapes, self.np_dtype, optimize=st["path"], replicas=R, device=device,
-                                      stream=self.tstream.cuda_stream, free_output_order=not root, in_strides=st_strides)
+                                      stream=self.stage_streams[k].cuda_stream, free_output_order=not root, in_strides=st_strides)
             self.stages.append({
                 "desc": st, "bc": bc, "R": R, "numel": stage_numel[k], "stride": stage_stride[k],
                 "out_term": st["out"] if root else bc.out_subscripts,
@@ -1673,11 +1680,30 @@ class StagedSlicedContraction:
         J = self._join
         root = self.stages[-1]
         ex = root["bc"].executor
-        with torch.cuda.stream(self.tstream):
-            for entry in self.schedule:
+        streams = self.stage_streams
+        concurrent = any(st is not self.tstream for st in streams)
+        if concurrent:                               # the side streams start behind everything the main one has been given
+            start = torch.cuda.Event()
+            start.record(self.tstream)
+            for st in set(streams):
+                if st is not self.tstream:
+                    st.wait_event(start)
+            done = {}                                # stage -> event behind its last entry
+            seen = set()
+        for entry in self.schedule:
+            k = entry[1]
+            if entry[0] == "merge":                  # (works on a child's buffer, on behalf of the root)
+                k = len(self.stages) - 1
+            stream = streams[k]
+            if concurrent and k not in seen:         # first entry of stage k: its operands' stages have finished
+                seen.add(k)
+                for kind, j in self.stage_desc[k]["operands"]:
+                    if kind == "st" and streams[j] is not stream:
+                        stream.wait_event(done[j])
+            with torch.cuda.stream(stream):
                 if entry[0] == "launch":
-                    _tag, k, launch, slot, n, resc = entry
-                    S = self.stages[k]
+                    _tag, k_, launch, slot, n, resc = entry
+                    S = self.stages[k_]
                     launch()
                     S["bc"].executor.snapshot_scales(S["c"].data_ptr() + 8 * slot, n, resc.data_ptr())
                 elif entry[0] == "merge":
@@ -1693,12 +1719,16 @@ class StagedSlicedContraction:
                     buf.mul_(torch.exp(cum - top).reshape(n, 1).to(buf.dtype))
                     S["cum"][:n] = top.expand(grid).reshape(n)
                 else:
-                    _tag, k, slot0, n, kids_idx = entry
-                    S = self.stages[k]
+                    _tag, k_, slot0, n, kids_idx = entry
+                    S = self.stages[k_]
                     cum = S["c"][slot0:slot0 + n]
                     for j, idx in kids_idx:
                         cum = cum + self.stages[j]["cum"].index_select(0, idx)
                     S["cum"][slot0:slot0 + n] = cum
+                    if concurrent:                   # ("cum" is a stage's last entry of a group)
+                        done[k_] = torch.cuda.Event()
+                        done[k_].record(stream)
+        with torch.cuda.stream(self.tstream):
             ex.combine_split(root["out"].data_ptr(), root["stride"], root["cum"].data_ptr(), 1, len(self.root_members),
                              J["numel"], J["packed"].data_ptr())
         self.tstream.synchronize()
