@@ -1048,8 +1048,10 @@ def test_nary_steps_and_optimize_false():
 @pytest.fixture
 def force_h_form(monkeypatch):
     """The launcher takes this form when a step is about one 128 x 128 tile per CU; these tests force it for every
-    eligible step (operands in 16-byte-request modes, K a multiple of 32)."""
+    eligible step (operands in 16-byte-request modes, K a multiple of 32) - and keep chains of epilogue-summed steps
+    on their per-site launches (no k_sweep_f32)."""
     monkeypatch.setenv("CTN_H", "1")
+    monkeypatch.setenv("CTN_SWEEP", "0")
     E.clear_caches()
     yield
     E.clear_caches()
