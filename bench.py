@@ -61,6 +61,8 @@ def parse_args():
     ap.add_argument("--no-batched", dest="with_batched", action="store_false",
                     help="mps: skip the secondary batched-MPS (BASELINE config 3b) measurement")
     ap.add_argument("--batch", type=int, default=4096, help="mps: inputs per GPU of that secondary")
+    ap.add_argument("--no-configs", dest="with_configs", action="store_false",
+                    help="mps: skip the `configs` object (BASELINE configs 1, 2, 3b at B = 1024 and 4 (i)-(iv), one GPU)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -112,7 +114,11 @@ def init_ranks(args):
     backend = os.environ.get("CTN_BENCH_BACKEND", "nccl")
     if os.environ.get("CTN_BENCH_ONE_DEVICE"):
         local_rank = 0
-    if world > 1:
+    # CTN_JOIN_WORLD1=1 under a one-rank launcher (`torch.distributed.run --nproc-per-node 1`): the process group is
+    # created although there is nobody to talk to, and the joins issue their collectives anyway (dist.join_alone) - on
+    # a one-GPU box this is the only way the RCCL path runs on hardware (tests/test_gpu_dist.py)
+    alone = world == 1 and os.environ.get("CTN_JOIN_WORLD1") == "1" and "RANK" in os.environ
+    if world > 1 or alone:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -161,13 +167,15 @@ def main():
             batched_secondary(args, result, world, rank, backend, dev)
         if args.with_peps and args.dtype == "f32":
             peps_secondary(args, result, world, rank, local_rank, backend, dev)
+        if args.with_configs and args.dtype == "f32" and world == 1:
+            configs_secondary(args, result, world, rank, backend, dev)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
-def batched_secondary(args, result, world, rank, backend, dev):
+def batched_secondary(args, result, world, rank, backend, dev, batch=None, out=None):
     """BASELINE config 3b next to the headline: `--batch` inputs per GPU through ONE 100-site MPS (D = 256, d = 4)
     hanging on a batch hyperedge - the reference paper's ML workload (README Fig. 1d).  Data-parallel over the
     batch (weak scaling, no collective on the data path: SURVEY.md 8e); value = inputs/s over all ranks.  On one
@@ -176,14 +184,15 @@ def batched_secondary(args, result, world, rank, backend, dev):
     import torch
     import torch.distributed as dist
 
-    out = result.setdefault("batched_mps", {}) if rank == 0 else {}
+    if out is None:
+        out = result.setdefault("batched_mps", {}) if rank == 0 else {}
     try:
         from contractn_amd import TN
         from contractn_amd.einsum import BatchedContraction, accumulate_log_scale
         from contractn_amd.paths import ssa_to_linear
         from tests import networks as nets
 
-        B, n_sites, bond, phys = args.batch, args.sites, args.bond, args.phys
+        B, n_sites, bond, phys = batch or args.batch, args.sites, args.bond, args.phys
 
         class Shape:
             def __init__(self, shape):
@@ -286,6 +295,158 @@ def batched_secondary(args, result, world, rank, backend, dev):
             out["error"] = repr(exc)
     finally:
         torch.cuda.empty_cache()
+
+
+def configs_secondary(args, result, world, rank, backend, dev):
+    """The other BASELINE configs in the driver's own line (round-3 verdict, item 2), one GPU, after the headline and
+    outside its timed region; every leg on its own try / except so that the headline never depends on them:
+
+    * cfg1 - README copy-tensor example (README.md:21-33): order-101 copy node + 100 vectors, fp64; device us per
+      contraction (HIP events), ms per `contract_fun` call, the known answer [1, 0.99^100];
+    * cfg2 - 1000 x (3 x 3) chain, split format (README.md:62-77): device us per step, the register's bits
+      (0x1.12a72fbccf574p+10);
+    * cfg3b_B1024 - the batched MPS at the smaller of the two batch sizes SURVEY.md 8d names;
+    * cfg4_i .. cfg4_iv - CP through a copy node, Tucker with a dense hub, Tucker with a MATERIALISED delta hub (must
+      equal 4 (i)), CP-wide r = 4096: TFLOP/s end to end, fraction of the fp32 MFMA peak, dominant kernel, an entry
+      against the definition in float64.
+    cfg3a is the headline itself (`value`, `latency`), cfg5 is `peps_strong_scaling`."""
+    import torch
+
+    if rank != 0:
+        return
+    cfgs = result.setdefault("configs", {"cfg3a": "the headline: `value`, `roofline`, `latency`",
+                                         "cfg5": "`peps_strong_scaling` (8 x 8 PEPS, D = 8 and D = 16)"})
+    from contractn_amd import TN
+    from contractn_amd import einsum as E
+    from contractn_amd.einsum import BatchedContraction
+
+    def leg(name, fn):
+        try:
+            cfgs[name] = fn()
+        except Exception as exc:  # noqa: BLE001 - recorded, the headline line must still be printed
+            cfgs[name] = {"error": repr(exc)}
+        finally:
+            torch.cuda.empty_cache()
+
+    def readme_example(which):
+        tn = TN()
+        if which == 1:
+            hub = tn.add_copy_node(101)
+            for i in range(100):
+                tn.connect_nodes(hub, tn.add_dense_node(np.array([1, 0.99])), i, 0)
+        else:
+            prev = tn.add_dense_node(np.ones(3))
+            for _ in range(1000):
+                mat = tn.add_dense_node(np.ones((3, 3)))
+                tn.connect_nodes(prev, mat, -1, 0)
+                prev = mat
+        fun = tn.make_contract_fun(split_format=True)
+        params = tn.params
+        t_hat, c = fun(params, ())
+        calls = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            fun(params, ())
+            calls.append(time.perf_counter() - t0)
+        bc = BatchedContraction(tn.einsum_str, [p.shape for p in params], np.float64, replicas=1, device=dev.index)
+        sets = [list(params)]
+        bc.run_host(sets)
+        bc.executor.set_timing(5)
+        for _ in range(5):
+            bc.run_host(sets)
+        dev_ms = float(bc.executor.step_ms().sum())
+        bc.executor.close()
+        out = {"steps": bc.plan.n_steps, "dtype": "f64", "call_ms_median": round(float(np.median(calls)) * 1e3, 4),
+               "device_us_per_contraction": round(dev_ms * 1e3, 2), "device_us_per_step": round(dev_ms * 1e3 / bc.plan.n_steps, 3),
+               "timing_mode": "HIP events around the launches of 5 passes (device); perf_counter around 20 contract_fun calls"}
+        full = np.asarray(t_hat, dtype=np.float64) * np.exp(float(c))
+        if which == 1:
+            want = np.array([1.0, 0.99 ** 100])
+            out["workload"] = "readme_copy_node_order101_100_vectors"
+            out["known_answer"] = {"ok": bool(np.allclose(full, want, rtol=1e-12)), "got": [float(x) for x in full],
+                                   "want": [float(x) for x in want], "source": "README.md:33"}
+            out["reference_published_ms"] = 6.85
+        else:
+            out["workload"] = "chain_1000x3x3_split_format"
+            out["known_answer"] = {"ok": bool(np.array_equal(np.asarray(t_hat), np.ones(3)) and float(c).hex() == "0x1.12a72fbccf574p+10"),
+                                   "t_hat": [float(x) for x in np.asarray(t_hat)], "log_scale": float(c),
+                                   "log_scale_hex": float(c).hex(), "want_hex": "0x1.12a72fbccf574p+10", "source": "README.md:73-76"}
+        return out
+
+    def cfg4(einstr, shapes, seed, scale, spot, hub=None):
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        ops = []
+        for i, sh in enumerate(shapes):
+            if hub == "delta" and i == 0:
+                t = torch.zeros(sh, device=dev)
+                idx = torch.arange(sh[0], device=dev)
+                t[idx, idx, idx] = 1.0
+            else:
+                t = torch.randn(sh, generator=gen, device=dev) / scale
+            ops.append(t)
+        bc = BatchedContraction(einstr, shapes, np.float32, optimize="auto", replicas=1, device=dev.index)
+        res = torch.empty(tuple(bc.plan.out_shape), device=dev)
+        torch.cuda.synchronize(dev)
+        launch = bc.executor.make_enqueue([t.data_ptr() for t in ops], [res.data_ptr()])
+        for _ in range(2):
+            launch()
+        bc.executor.synchronize()
+        K = 3
+        t0 = time.perf_counter()
+        for _ in range(K):
+            launch()
+        bc.executor.synchronize()
+        sec = (time.perf_counter() - t0) / K
+        bc.executor.set_timing(2)
+        for _ in range(2):
+            launch()
+        bc.executor.synchronize()
+        ms = bc.executor.step_ms().astype(np.float64)
+        bc.executor.set_timing(0)
+        infos, tiles = bc.plan.step_infos(), bc.executor.step_tiles()
+        c = float(bc.fetch_log_scale()[0])
+        dom = int(np.argmax(ms))
+        key = (infos[dom]["kernel"], infos[dom]["mode_a"], infos[dom]["mode_b"], tiles[dom][0], tiles[dom][1])
+        dom_flops = infos[dom]["flops"] + sum(i["flops"] for i in infos if i["kernel"] == 5)   # absorbed steps run inside it
+        got, ref, peak_abs = spot(ops, res, c)
+        out = {"workload": einstr, "shapes": [list(sh) for sh in shapes], "ms_per_contraction": round(sec * 1e3, 3),
+               "flop_per_contraction": bc.plan.flops, "achieved_tflops": round(bc.plan.flops / sec / 1e12, 2),
+               "frac_of_mfma_peak": round(bc.plan.flops / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+               "steps": [{"kernel": kernel_label((i["kernel"], i["mode_a"], i["mode_b"], tl[0], tl[1])), "ms": round(float(m), 3)}
+                         for i, tl, m in zip(infos, tiles, ms)],
+               "dominant_kernel": {"kernel": kernel_label(key), "avg_launch_ms": round(float(ms[dom]), 3),
+                                   "achieved": round(dom_flops / (ms[dom] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                                   "frac": round(dom_flops / (ms[dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+               "spot_check_vs_definition_f64": {"ok": bool(abs(got - ref) <= 1e-3 * peak_abs), "got": got, "want": ref,
+                                                "tolerance": "1e-3 of the largest |entry|"},
+               "timing_mode": f"perf_counter around {K} enqueues + synchronize (hipGraph replay); per step: HIP events, 2 more passes"}
+        bc.executor.close()
+        return out
+
+    def spot_cp(ops, res, c, e=(5, 700, 1023)):
+        A, B, C = ops[-3:]
+        ref = float((A[:, e[0]].double() * B[:, e[1]].double() * C[:, e[2]].double()).sum())
+        scale = float(np.exp(c))
+        return float(res[e]) * scale, ref, float(res.abs().max()) * scale
+
+    def spot_tucker(ops, res, c, e=(5, 700, 1023)):
+        H, A, B, C = ops
+        v = torch.einsum("abc,c->ab", H.double(), C[:, e[2]].double())
+        ref = float(A[:, e[0]].double() @ v @ B[:, e[1]].double())
+        scale = float(np.exp(c))
+        return float(res[e]) * scale, ref, float(res.abs().max()) * scale
+
+    leg("cfg1", lambda: readme_example(1))
+    leg("cfg2", lambda: readme_example(2))
+    b1024 = {}
+    batched_secondary(args, result, world, rank, backend, dev, batch=1024, out=b1024)
+    cfgs["cfg3b_B1024"] = b1024
+    n = 1024
+    leg("cfg4_i_cp_hyper", lambda: cfg4("ac,ad,ae->cde", [(n, n)] * 3, 5, 32.0, spot_cp))
+    leg("cfg4_ii_tucker_dense_hub", lambda: cfg4("abc,ae,bf,cg->efg", [(n, n, n)] + [(n, n)] * 3, 7, 32.0, spot_tucker))
+    leg("cfg4_iii_tucker_delta_hub", lambda: cfg4("abc,ae,bf,cg->efg", [(n, n, n)] + [(n, n)] * 3, 5, 32.0, spot_cp, hub="delta"))
+    leg("cfg4_iv_cp_wide_r4096", lambda: cfg4("ac,ad,ae->cde", [(4096, n)] * 3, 9, 64.0, spot_cp))
 
 
 def peps_secondary(args, result, world, rank, local_rank, backend, dev):
@@ -627,11 +788,13 @@ def run_peps(args, world, rank, local_rank, backend, dev):
     execs = [st[0].executor for st in stages]
     max_chunks = max([st[3] for st in stages], default=1)
 
+    pg = dist.is_available() and dist.is_initialized()      # (also at world 1 under CTN_JOIN_WORLD1=1, see init_ranks)
+
     def sync_all():
         for x in execs:
             x.synchronize()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if pg:
             dist.barrier()
 
     # (an executor replays its launch sequence as a hipGraph from its third enqueue on: at least two eager ones first)
@@ -658,7 +821,7 @@ def run_peps(args, world, rank, local_rank, backend, dev):
         x.set_timing(0)
     # evaluations per stage over all ranks (a stage below no sliced label is evaluated by every rank: counted each time)
     evals_all = torch.tensor([float(st[1]) for st in stages], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-    if world > 1:
+    if pg:
         tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -792,6 +955,8 @@ def run_peps(args, world, rank, local_rank, backend, dev):
             "parallelism": f"index slicing x{world}, one all_gather of (T_hat, c) per contraction",
         },
         "achieved_tflops": round(tflops, 3),
+        "collectives": {"process_group": bool(pg), "backend": (dist.get_backend() if pg else None), "world": world,
+                        "join_all_gather_per_contraction": bool(world > 1 or cdist.join_alone())},
         "result": {"t_hat": float(t_hat), "log_scale": float(log_scale)},
         "roofline": roofline,
         "device": dict(device_info(dev), **under_load),

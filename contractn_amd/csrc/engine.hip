@@ -203,6 +203,8 @@ struct Exec {
   std::vector<LeafGroup> groups;    // per step: len >= 2 at the head of a group, else 0
   StepArgs* h_group_args = nullptr; // pinned: the one-time upload may fall inside a stream capture
   StepArgs* d_group_args = nullptr;
+  char* d_merge = nullptr;          // ctn_exec_merge_scales: liveness flags + new registers, grown on demand
+  size_t merge_bytes = 0;
   int timing_slots = 0;             // 0 = timing off
   int timing_runs = 0;              // enqueues recorded since timing was enabled
   std::vector<hipEvent_t> events;   // [slot][step][2]
@@ -213,7 +215,8 @@ struct Exec {
                     (void*)d_log, (void*)d_resc, (void*)d_logs, (void*)d_chain, d_ones, (void*)d_stepP, (void*)d_stepNumel,
                     (void*)d_stepOff, (void*)d_stepSlots,
                     (void*)d_stage_in, (void*)d_stage_out, (void*)d_group_args, (void*)d_sweep_ids, (void*)d_sweep_off,
-                    (void*)d_sweep_slots, (void*)d_sweep_a, (void*)d_sweep_s, (void*)d_sweep_z, (void*)d_sweep_la, (void*)d_sweep_ls})
+                    (void*)d_sweep_slots, (void*)d_sweep_a, (void*)d_sweep_s, (void*)d_sweep_z, (void*)d_sweep_la, (void*)d_sweep_ls,
+                    (void*)d_merge})
       if (p) (void)hipFree(p);
     if (h_pack) (void)hipHostFree(h_pack);
     if (h_group_args) (void)hipHostFree(h_group_args);
@@ -622,11 +625,15 @@ static bool sweep_match(const Plan& P, Exec::SweepDesc* d) {
     std::vector<int> run{s0};
     last = first;
     for (int s = s0 + 1; s < P.n_steps; ++s) {
+      // Only markers of absorbed steps (nothing is launched for them) may lie between two members: the ONE launch of
+      // the run sits at its last member's position and reads the first member's input there, which the plan's arena
+      // released right after the first member - any launched step in between (the other half of an interleaved
+      // left / right chain, say) could have been given that region.  Such a step ends the run.
+      if (P.steps[s].kernel == CTN_KERNEL_FUSED) continue;
       if (P.steps[s].lhs != P.steps[run.back()].out && P.steps[s].rhs != P.steps[run.back()].out &&
           P.steps[s].lhs2 != P.steps[run.back()].out)
-        continue;
+        break;
       // the consumer of the run's last result: a member if it has the same shape and takes it as its E
-      if (P.steps[s].kernel == CTN_KERNEL_FUSED) continue;   // (the marker of the GEMM the member absorbed)
       if (P.steps[s].lhs == P.steps[run.back()].out && sweep_step_shape(P, s, &cur) && cur.M == first.M && cur.D == first.D &&
           cur.Pd == first.Pd && cur.ldWl == first.ldWl && cur.ldWp == first.ldWp && cur.ldX == first.ldX && cur.ldA == last.ldC) {
         run.push_back(s);
@@ -639,6 +646,20 @@ static bool sweep_match(const Plan& P, Exec::SweepDesc* d) {
     if (run.size() > best.size()) { best = run; best_first = first; best_last = last; }
   }
   if (best.size() < 2) return false;
+  {
+    // the run's result must not land on its own input: blocks of rows start and finish at different times (a launch of
+    // more than one round of workgroups), so a block's result rows may only cover ITS OWN input rows - the same region
+    // with the same row stride - or nothing of the input at all
+    const int idIn = P.steps[best.front()].lhs, idOut = P.steps[best.back()].out;
+    const bool in_ws = idIn >= P.n_inputs, out_ws = idOut < P.n_inputs + P.n_steps - 1;
+    if (in_ws && out_ws) {
+      const int64_t es = P.elem_size();
+      const int64_t a0 = P.tensors[idIn].ws_offset, a1 = a0 + ((best_first.M - 1) * best_first.ldA + best_first.D) * es;
+      const int64_t b0 = P.tensors[idOut].ws_offset, b1 = b0 + ((best_first.M - 1) * best_last.ldC + best_first.D) * es;
+      const bool overlap = a0 < b1 && b0 < a1;
+      if (overlap && !(a0 == b0 && best_first.ldA == best_last.ldC)) return false;
+    }
+  }
   d->on = true; d->steps = best;
   d->ldIn = best_first.ldA; d->ldOut = best_last.ldC; d->ldWl = best_first.ldWl; d->ldWp = best_first.ldWp; d->ldX = best_first.ldX;
   d->J = (int)((best_first.M + SWR - 1) / SWR); d->M = (int)best_first.M; d->D = best_first.D; d->Pd = best_first.Pd;
@@ -1504,6 +1525,7 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
       Exec::ZipDesc z;
       if (E.zip_skip[s - 1] || (s >= 2 && E.zip[s - 1].on) || !zip_match(P, s, &z)) continue;
       if (E.sw.zip != 1 && (int64_t)(z.U / ZU) * replicas < E.n_cu) continue;
+      if (z.U / ZU > kMaxPartials) continue;    // (one abs-sum partial per workgroup: the consumers add at most that many)
       E.zip[s] = z;
       E.zip_skip[s - 1] = 1;
       any = true;
@@ -1852,6 +1874,15 @@ int ctn_exec_scales_suspect(const ctn_exec* exec, const double* host_rescales, i
   return exec_scales_suspect(&exec->e, host_rescales, replicas) ? 1 : 0;
 }
 
+int ctn_exec_report_suspect(ctn_exec* exec, int suspect) {
+  if (!exec) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+  Exec* E = &exec->e;
+  if (E->eager_forced) return E->eager_streak;
+  E->eager_streak = suspect ? E->eager_streak + 1 : (E->eager_streak >= kEagerSticky ? E->eager_streak : 0);
+  if (E->eager_streak >= kEagerSticky) E->eager_rescale = true;     // exec_new_run keeps it from now on
+  return E->eager_streak;
+}
+
 int ctn_exec_combine_split(ctn_exec* exec, int t_dtype, const void* t, int64_t t_stride, const double* c,
                            int64_t c_stride, int n, int64_t numel, double* out_packed) {
   if (!exec || !t || !c || !out_packed || n < 1 || numel < 1) { g_err = "invalid argument to ctn_exec_combine_split"; return CTN_INVALID_ARG; }
@@ -1867,6 +1898,82 @@ int ctn_exec_combine_split(ctn_exec* exec, int t_dtype, const void* t, int64_t t
     hipLaunchKernelGGL(k_combine_split<double>, dim3(1), dim3(256), 0, E->stream, (const double*)t, t_stride, c, c_stride, n,
                        numel, E->plan->min_norm, out_packed);
   HIPCHECK(hipGetLastError());
+  return CTN_OK;
+}
+
+int ctn_exec_add_scales(ctn_exec* exec, double* dst, const double* own, int n, int n_kids, const double* const* kid_scales,
+                        const int64_t* const* kid_index) {
+  if (!exec || !dst || !own || n < 0 || n_kids < 0 || (n_kids && (!kid_scales || !kid_index))) {
+    g_err = "invalid argument to ctn_exec_add_scales";
+    return CTN_INVALID_ARG;
+  }
+  if (n == 0) return CTN_OK;
+  Exec* E = &exec->e;
+  DeviceGuard dg(E->device);
+  HIPCHECK(dg.err);
+  const double* src = own;
+  int done = 0;
+  do {                                           // (more than 8 stages below one: several launches, dst carried along)
+    ScalesAddArgs a{};
+    a.dst = dst; a.own = src; a.n = n;
+    a.n_kids = std::min(kScalesAddMaxKids, n_kids - done);
+    for (int j = 0; j < a.n_kids; ++j) {
+      if (!kid_scales[done + j] || !kid_index[done + j]) { g_err = "ctn_exec_add_scales: NULL child array"; return CTN_INVALID_ARG; }
+      a.kid[j] = kid_scales[done + j]; a.idx[j] = kid_index[done + j];
+    }
+    hipLaunchKernelGGL(k_scales_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, E->stream, a);
+    done += a.n_kids;
+    src = dst;
+  } while (done < n_kids);
+  HIPCHECK(hipGetLastError());
+  return CTN_OK;
+}
+
+int ctn_exec_merge_scales(ctn_exec* exec, int t_dtype, void* buf, int64_t stride, int64_t numel, double* scales, int n,
+                          int ndim, const int32_t* extents, const int32_t* merged) {
+  if (!exec || !buf || !scales || n < 1 || numel < 1 || stride < numel || ndim < 1 || ndim > kMergeMaxDims || !extents || !merged) {
+    g_err = "invalid argument to ctn_exec_merge_scales";
+    return CTN_INVALID_ARG;
+  }
+  if (t_dtype != CTN_F32 && t_dtype != CTN_F64) { g_err = "ctn_exec_merge_scales: dtype must be f32 or f64"; return CTN_UNSUPPORTED; }
+  const int esz = t_dtype == CTN_F32 ? 4 : 8;
+  if ((uintptr_t)buf % 16 || (stride * esz) % 16) { g_err = "ctn_exec_merge_scales: evaluations must start on 16-byte boundaries"; return CTN_INVALID_ARG; }
+  int64_t cells = 1;
+  for (int d = 0; d < ndim; ++d) { if (extents[d] < 1) { g_err = "ctn_exec_merge_scales: empty axis"; return CTN_INVALID_ARG; } cells *= extents[d]; }
+  if (cells != n || n > 65535) { g_err = "ctn_exec_merge_scales: the grid of evaluations does not match n (<= 65535)"; return CTN_INVALID_ARG; }
+  Exec* E = &exec->e;
+  DeviceGuard dg(E->device);
+  HIPCHECK(dg.err);
+  const size_t need = (size_t)n * 16;
+  if (E->merge_bytes < need) {
+    if (E->d_merge) { HIPCHECK(hipStreamSynchronize(E->stream)); (void)hipFree(E->d_merge); E->d_merge = nullptr; E->merge_bytes = 0; }
+    hipError_t e_ = hipMalloc((void**)&E->d_merge, need);
+    if (e_ != hipSuccess) { g_err = "hipMalloc(merge scratch) failed"; return e_ == hipErrorOutOfMemory ? CTN_OOM : CTN_HIP_ERROR; }
+    E->merge_bytes = need;
+  }
+  double* cum_new = (double*)E->d_merge;
+  int32_t* flags = (int32_t*)(E->d_merge + (size_t)n * 8);
+  HIPCHECK(hipMemsetAsync(flags, 0, (size_t)n * 4, E->stream));
+  // an evaluation is cut into chunks of whole 16-byte vectors; enough workgroups to fill the chip, at most 4096 per evaluation
+  const int64_t per_wg = 256 * 16;
+  int64_t chunks = std::min<int64_t>(4096, std::max<int64_t>(1, (numel + per_wg - 1) / per_wg));
+  chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, std::max<int64_t>(1, (8LL * E->n_cu + n - 1) / n)));
+  const int64_t chunk = ((numel + chunks - 1) / chunks + 1023) / 1024 * 1024;
+  chunks = (numel + chunk - 1) / chunk;
+  const dim3 grid((unsigned)chunks, (unsigned)n);
+  MergeArgs a{};
+  a.buf = buf; a.stride = stride; a.numel = numel; a.chunk = chunk; a.cum = scales; a.cum_new = cum_new; a.flags = flags;
+  a.n = n; a.ndim = ndim;
+  for (int d = 0; d < ndim; ++d) { a.ext[d] = extents[d]; a.merged[d] = merged[d] ? 1 : 0; }
+  if (t_dtype == CTN_F32) {
+    hipLaunchKernelGGL(k_merge_live<float>, grid, dim3(256), 0, E->stream, (const float*)buf, stride, numel, chunk, flags);
+    hipLaunchKernelGGL(k_merge_scale<float>, grid, dim3(256), 0, E->stream, a);
+  } else {
+    hipLaunchKernelGGL(k_merge_live<double>, grid, dim3(256), 0, E->stream, (const double*)buf, stride, numel, chunk, flags);
+    hipLaunchKernelGGL(k_merge_scale<double>, grid, dim3(256), 0, E->stream, a);
+  }
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(scales, cum_new, (size_t)n * 8, hipMemcpyDeviceToDevice, E->stream));
   return CTN_OK;
 }
 

@@ -587,6 +587,102 @@ __global__ __launch_bounds__(256) void k_combine_split(const TIN* __restrict__ t
 }
 
 // ---------------------------------------------------------------------------
+// Scale bookkeeping of a sliced contraction run in stages (dist.StagedSlicedContraction; no reference counterpart -
+// the reference is a single process on one unsliced network): the results of a lower stage are operands of the stages
+// above, and their log-scale registers ride along.
+//
+// k_scales_add: dst[i] = own[i] + sum_j kid_j[idx_j[i]], added left to right - the register of evaluation i of a stage
+// plus those of the evaluations of the stages below that it consumed.
+// ---------------------------------------------------------------------------
+constexpr int kScalesAddMaxKids = 8;
+struct ScalesAddArgs {
+  double* dst;
+  const double* own;
+  int32_t n, n_kids;
+  const double* kid[kScalesAddMaxKids];
+  const int64_t* idx[kScalesAddMaxKids];
+};
+__global__ __launch_bounds__(256) void k_scales_add(ScalesAddArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  double v = a.own[i];
+  for (int j = 0; j < a.n_kids; ++j) v += a.kid[j][a.idx[j][i]];
+  a.dst[i] = v;
+}
+
+// k_merge_live / k_merge_scale: the n evaluations of a stage lie on a grid over the sliced labels the stage depends on
+// (`ext[0..ndim)`, row-major); along the axes flagged in `merged` they are about to become ONE strided operand of the
+// root stage, so every group of evaluations that differ only along those axes is brought to its common scale - the
+// largest register among the members that are not exact zeros (the liveness rule of k_combine_split: the WHOLE tensor
+// is looked at; a live tensor is recognised by whichever workgroup sees its first non-zero, an all-zero one costs a
+// full scan) - by multiplying member i with e^{c_i - top}; the new register of every member is `top` (0 when the whole
+// group is zero).  Exact zeros are left alone.  `cum_new` is a separate array: members of a group read each other's
+// old registers.
+template <typename T>
+__global__ __launch_bounds__(256) void k_merge_live(const T* __restrict__ buf, int64_t stride, int64_t numel, int64_t chunk,
+                                                    int32_t* __restrict__ flags) {
+  const int i = blockIdx.y;
+  if (__builtin_nontemporal_load(flags + i)) return;      // somebody has already found a non-zero
+  const T* __restrict__ p = buf + (size_t)i * stride;
+  const int64_t j0 = (int64_t)blockIdx.x * chunk, j1 = min(numel, j0 + chunk);
+  bool nz = false;
+  for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
+    nz = p[j] != (T)0;
+    if (__ballot(nz) != 0ull) { nz = true; break; }
+  }
+  if (nz && (threadIdx.x & 63) == 0) flags[i] = 1;
+}
+
+constexpr int kMergeMaxDims = 8;
+struct MergeArgs {
+  void* buf;
+  int64_t stride, numel, chunk;
+  const double* cum;
+  double* cum_new;
+  const int32_t* flags;
+  int32_t n, ndim;
+  int32_t ext[kMergeMaxDims], merged[kMergeMaxDims];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_merge_scale(MergeArgs a) {
+  __shared__ double s_top;
+  const int i = blockIdx.y;
+  if (threadIdx.x == 0) {
+    int coord[kMergeMaxDims], rem = i;
+    for (int d = a.ndim - 1; d >= 0; --d) { coord[d] = rem % a.ext[d]; rem /= a.ext[d]; }
+    int members = 1;
+    for (int d = 0; d < a.ndim; ++d) if (a.merged[d]) members *= a.ext[d];
+    double top = -INFINITY;
+    for (int mbr = 0; mbr < members; ++mbr) {
+      int r2 = mbr, idx = 0;
+      int c2[kMergeMaxDims];
+      for (int d = a.ndim - 1; d >= 0; --d) {
+        if (a.merged[d]) { c2[d] = r2 % a.ext[d]; r2 /= a.ext[d]; } else c2[d] = coord[d];
+      }
+      for (int d = 0; d < a.ndim; ++d) idx = idx * a.ext[d] + c2[d];
+      if (a.flags[idx]) top = fmax(top, a.cum[idx]);
+    }
+    s_top = top == -INFINITY ? 0.0 : top;
+    if (blockIdx.x == 0) a.cum_new[i] = s_top;
+  }
+  __syncthreads();
+  if (!a.flags[i]) return;                                   // an exact zero stays one
+  const T f = (T)exp(a.cum[i] - s_top);
+  if (f == (T)1) return;
+  T* __restrict__ p = (T*)a.buf + (size_t)i * a.stride;
+  const int64_t j0 = (int64_t)blockIdx.x * a.chunk, j1 = min(a.numel, j0 + a.chunk);
+  constexpr int V = 16 / (int)sizeof(T);                     // (stride and chunk are multiples of V: 16-byte accesses)
+  typedef T vecT __attribute__((ext_vector_type(V)));
+  const int64_t jv = j0 + (j1 - j0) / V * V;
+  for (int64_t j = j0 + (int64_t)threadIdx.x * V; j < jv; j += 256 * V) {
+    vecT v = *reinterpret_cast<vecT*>(p + j);
+    v *= f;
+    *reinterpret_cast<vecT*>(p + j) = v;
+  }
+  for (int64_t j = jv + threadIdx.x; j < j1; j += 256) p[j] *= f;
+}
+
+// ---------------------------------------------------------------------------
 // K-chain: persistent small-tensor DAG walker.  One workgroup per replica executes EVERY step of
 // the plan in order (reference loop einsum.py:341-391) - no per-step launch, rescale factors of
 // all produced tensors kept in LDS.  Same arithmetic as k_element (operands divided by their

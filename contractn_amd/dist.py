@@ -717,7 +717,10 @@ class SlicedContraction:
     """
 
     def __init__(self, einstr, operands, slice_labels, optimize="auto", rank=0, world=1, device=0,
-                 dtype=None, workspace_budget=64 << 30):
+                 dtype=None, workspace_budget=64 << 30, slices=None):
+        """``slices``: the joint values of ``slice_labels`` this rank contracts (tuples), instead of its contiguous
+        share of all of them - for a caller that has dealt the slices itself (`StagedSlicedContraction` cuts the grid of
+        label values into blocks; its checked fallback must cover exactly its own block)."""
         import torch
 
         from . import einsum as E
@@ -749,7 +752,12 @@ class SlicedContraction:
         self.sizes = sizes
         ranges = [range(sizes[lab]) for lab in self.slice_labels]
         all_slices = list(itertools.product(*ranges))
-        self.my_slices = [all_slices[i] for i in shard_range(len(all_slices), rank, world)]
+        if slices is None:
+            self.my_slices = [all_slices[i] for i in shard_range(len(all_slices), rank, world)]
+        else:
+            self.my_slices = [tuple(int(x) for x in v) for v in slices]
+            if any(len(v) != len(ranges) or any(x not in rg for x, rg in zip(v, ranges)) for v in self.my_slices):
+                raise ValueError("slices must be joint values of the sliced labels")
         self.out_shape = tuple(sizes[s] for s in out)
         self.n_total = len(all_slices)
         self.device = device
@@ -949,7 +957,7 @@ class SlicedContraction:
         import torch.distributed as dist
 
         t_loc, c_loc = self.local_result_device()
-        if self.world == 1:
+        if self.world == 1 and not join_alone():
             return t_loc, (0.0 if c_loc is None else c_loc)
         backend = dist.get_backend(group)
         on_dev = backend == "nccl"
@@ -985,6 +993,17 @@ class SlicedContraction:
         return full.reshape(self.out_shape), c
 
 
+def join_alone():
+    """``CTN_JOIN_WORLD1=1``: a single rank whose process group exists still issues the collectives of the joins
+    (`join_packed`'s all_gather, `run_device`'s reduce-scatter + all_reduce + all-gather) - on a one-GPU box this is how
+    the RCCL path is executed on hardware at all (tests/test_gpu_dist.py, `bench.py` under a one-rank launcher)."""
+    if os.environ.get("CTN_JOIN_WORLD1") != "1":
+        return False
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized()
+
+
 def join_packed(ex, J, world, group, dev):
     """The cross-rank half of the device-side join: ``J["packed"]`` (this rank's ``numel + 1`` doubles, complete and
     visible: the executor's stream has been waited for) -> ONE ``all_gather`` -> `k_combine_split` over the ``world``
@@ -994,7 +1013,7 @@ def join_packed(ex, J, world, group, dev):
 
     numel = J["numel"]
     result = J["packed"]
-    if world > 1:
+    if world > 1 or join_alone():
         if dist.get_backend(group) == "nccl":
             dist.all_gather_into_tensor(J["gathered"], J["packed"], group=group)      # THE join
         else:   # gloo (CPU tests, one-GPU rehearsals): the same buffer crosses through the host
@@ -1700,46 +1719,48 @@ class StagedSlicedContraction:
                 for kind, j in self.stage_desc[k]["operands"]:
                     if kind == "st" and streams[j] is not stream:
                         stream.wait_event(done[j])
-            with torch.cuda.stream(stream):
-                if entry[0] == "launch":
-                    _tag, k_, launch, slot, n, resc = entry
-                    S = self.stages[k_]
-                    launch()
-                    S["bc"].executor.snapshot_scales(S["c"].data_ptr() + 8 * slot, n, resc.data_ptr())
-                elif entry[0] == "merge":
-                    # the evaluations of stage j along the un-sliced axes become ONE operand of the root: bring them to
-                    # their common (largest) scale - exact zeros aside - and let that scale ride along
-                    _tag, j, n, grid, axes = entry
-                    S = self.stages[j]
-                    buf = S["out"][:n]
-                    cum = S["cum"][:n].reshape(grid)
-                    live = buf[:, :min(64, S["numel"])].ne(0).any(dim=1).reshape(grid)
-                    top = torch.where(live, cum, torch.full_like(cum, float("-inf"))).amax(dim=axes, keepdim=True)
-                    top = torch.where(torch.isinf(top), torch.zeros_like(top), top)
-                    buf.mul_(torch.exp(cum - top).reshape(n, 1).to(buf.dtype))
-                    S["cum"][:n] = top.expand(grid).reshape(n)
-                else:
-                    _tag, k_, slot0, n, kids_idx = entry
-                    S = self.stages[k_]
-                    cum = S["c"][slot0:slot0 + n]
-                    for j, idx in kids_idx:
-                        cum = cum + self.stages[j]["cum"].index_select(0, idx)
-                    S["cum"][slot0:slot0 + n] = cum
-                    if concurrent:                   # ("cum" is a stage's last entry of a group)
-                        done[k_] = torch.cuda.Event()
-                        done[k_].record(stream)
-        with torch.cuda.stream(self.tstream):
-            ex.combine_split(root["out"].data_ptr(), root["stride"], root["cum"].data_ptr(), 1, len(self.root_members),
-                             J["numel"], J["packed"].data_ptr())
+            if entry[0] == "launch":
+                _tag, k_, launch, slot, n, resc = entry
+                S = self.stages[k_]
+                launch()
+                S["bc"].executor.snapshot_scales(S["c"].data_ptr() + 8 * slot, n, resc.data_ptr())
+            elif entry[0] == "merge":
+                # the evaluations of stage j along the un-sliced axes become ONE operand of the root: bring them to
+                # their common (largest) scale - exact zeros aside - and let that scale ride along (one launch pair on
+                # the root's stream: ctn_exec_merge_scales)
+                _tag, j, n, grid, axes = entry
+                S = self.stages[j]
+                ex.merge_scales(S["out"].data_ptr(), S["stride"], S["numel"], S["cum"].data_ptr(), n, grid,
+                                [q in axes for q in range(len(grid))])
+            else:
+                # cum = own register + those of the children's evaluations it consumed (ctn_exec_add_scales, on the
+                # stage's own stream)
+                _tag, k_, slot0, n, kids_idx = entry
+                S = self.stages[k_]
+                S["bc"].executor.add_scales(S["cum"].data_ptr() + 8 * slot0, S["c"].data_ptr() + 8 * slot0, n,
+                                            [(self.stages[j]["cum"].data_ptr(), idx.data_ptr()) for j, idx in kids_idx])
+                if concurrent:                   # ("cum" is a stage's last entry of a group)
+                    done[k_] = torch.cuda.Event()
+                    done[k_].record(stream)
+        ex.combine_split(root["out"].data_ptr(), root["stride"], root["cum"].data_ptr(), 1, len(self.root_members),
+                         J["numel"], J["packed"].data_ptr())
         self.tstream.synchronize()
-        suspect = any(self.stages[e[1]]["bc"].executor.scales_suspect(e[5].data_ptr(), e[4]) for e in self.schedule if e[0] == "launch")
+        verdict = [False] * len(self.stages)
+        for e in self.schedule:
+            if e[0] == "launch" and not verdict[e[1]]:
+                verdict[e[1]] = self.stages[e[1]]["bc"].executor.scales_suspect(e[5].data_ptr(), e[4])
+        for S, v in zip(self.stages, verdict):           # (a stage that keeps being suspect goes eager for good)
+            S["bc"].executor.report_suspect(v)
+        suspect = any(verdict)
         if suspect:
-            # a lazily rescaled product left the dtype's range somewhere: the whole contraction again on the plain,
-            # checked path (per-slice fetch repeats such a group with eager rescaling); every rank still joins once
+            # a lazily rescaled product left the dtype's range somewhere: THIS RANK'S BLOCK of slices again on the plain,
+            # checked path (per-slice fetch repeats such a group with eager rescaling; `slices=`: exactly the block the
+            # staged form dealt to this rank, whatever the other ranks do); every rank still joins once
             if self._plain is None:
                 einstr, operands, labels, path, dtype, budget = self._args
                 self._plain = SlicedContraction(einstr, operands, labels, optimize=path, rank=self.rank, world=self.world,
-                                                device=self.device, dtype=dtype, workspace_budget=budget)
+                                                device=self.device, dtype=dtype, workspace_budget=budget,
+                                                slices=self.my_slices)
             t_loc, c_loc = self._plain.local_result()
             host = np.concatenate([np.asarray(t_loc, dtype=np.float64).ravel(), [float(c_loc)]])
             J["packed"].copy_(torch.from_numpy(host))

@@ -39,6 +39,7 @@ ABI_SYMBOLS = (
     "ctn_exec_fetch", "ctn_exec_synchronize", "ctn_exec_set_timing", "ctn_exec_step_ms",
     "ctn_exec_step_tile", "ctn_exec_set_rescale_mode", "ctn_exec_eager_reruns",
     "ctn_exec_snapshot_scales", "ctn_exec_scales_suspect", "ctn_exec_combine_split",
+    "ctn_exec_add_scales", "ctn_exec_merge_scales", "ctn_exec_report_suspect",
 )
 
 
@@ -158,6 +159,9 @@ def load_library():
         "ctn_exec_snapshot_scales": (i32, [vp, vp, i32, vp]),
         "ctn_exec_scales_suspect": (i32, [vp, vp, i32]),
         "ctn_exec_combine_split": (i32, [vp, i32, vp, i64, vp, i64, i32, i64, vp]),
+        "ctn_exec_report_suspect": (i32, [vp, i32]),
+        "ctn_exec_add_scales": (i32, [vp, vp, vp, i32, i32, C.POINTER(vp), C.POINTER(vp)]),
+        "ctn_exec_merge_scales": (i32, [vp, i32, vp, i64, i64, vp, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -428,6 +432,11 @@ class Executor:
         """The range check of ``fetch`` on rescale factors already on the host (``replicas * n_steps`` doubles)."""
         return bool(_check(self._lib.ctn_exec_scales_suspect(self._h, C.c_void_p(host_resc_ptr), int(replicas))))
 
+    def report_suspect(self, suspect):
+        """Tell the executor the verdict of a run whose scales the caller checked itself (no fetch): after three suspect
+        runs in a row it stays in eager mode.  Returns the streak."""
+        return _check(self._lib.ctn_exec_report_suspect(self._h, 1 if suspect else 0))
+
     def combine_split(self, t_ptr, t_stride, c_ptr, c_stride, n, numel, out_ptr, dtype=None):
         """Enqueue ``out[0:numel], out[numel] = (T_hat, c)`` of ``sum_i t_i exp(c_i)`` over ``n`` parts (device
         pointers; ``t`` of ``dtype``, default the plan's; ``c`` and ``out`` float64)."""
@@ -435,6 +444,23 @@ class Executor:
         _check(self._lib.ctn_exec_combine_split(self._h, CTN_F32 if dt == np.float32 else CTN_F64, C.c_void_p(t_ptr),
                                                 int(t_stride), C.c_void_p(c_ptr), int(c_stride), int(n), int(numel),
                                                 C.c_void_p(out_ptr)))
+
+    def add_scales(self, dst_ptr, own_ptr, n, kids=()):
+        """Enqueue ``dst[i] = own[i] + sum_j kid_j[idx_j[i]]`` over ``n`` float64 registers (device pointers; ``kids``:
+        ``[(scales_ptr, int64_index_ptr)]``, added in order) - the registers of the stages below ride along."""
+        k = len(kids)
+        sc = (C.c_void_p * max(k, 1))(*[p for p, _ in kids])
+        ix = (C.c_void_p * max(k, 1))(*[p for _, p in kids])
+        _check(self._lib.ctn_exec_add_scales(self._h, C.c_void_p(dst_ptr), C.c_void_p(own_ptr), int(n), k, sc, ix))
+
+    def merge_scales(self, buf_ptr, stride, numel, scales_ptr, n, extents, merged, dtype=None):
+        """Enqueue: the ``n`` evaluations at ``buf + i * stride`` (grid ``extents``, row-major) are brought to a common
+        scale along the axes flagged in ``merged`` (include/ctn_abi.h, ctn_exec_merge_scales)."""
+        dt = self.plan.np_dtype if dtype is None else np.dtype(dtype)
+        ext, mrg = _i32(extents), _i32(1 if m else 0 for m in merged)
+        _check(self._lib.ctn_exec_merge_scales(self._h, CTN_F32 if dt == np.float32 else CTN_F64, C.c_void_p(buf_ptr),
+                                               int(stride), int(numel), C.c_void_p(scales_ptr), int(n), len(ext),
+                                               _ptr(ext, C.c_int32), _ptr(mrg, C.c_int32)))
 
     def set_timing(self, slots):
         """Bracket every step of the next ``slots`` enqueues with HIP events (0 = off)."""

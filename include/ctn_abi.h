@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CTN_ABI_VERSION 4
+#define CTN_ABI_VERSION 5
 
 typedef enum {
   CTN_OK = 0,
@@ -163,7 +163,16 @@ void ctn_exec_destroy(ctn_exec* exec);
  *   log_scale      host [replicas]: sum over steps of log(rescale), accumulated on the device
  *   step_rescales  host [replicas * n_steps] or NULL: the rescale factor of every step
  *                  (0.0 where the step was not rescaled) so the caller can redo the
- *                  log accumulation in the reference's exact order and precision
+ *                  log accumulation in the reference's exact order and precision.
+ *                  The PRODUCT of the factors (the register, and with it (T_hat, c)) is the reference's; the
+ *                  factor of an individual step is the reference's own (what cpu_ref.core_contract(record=True)
+ *                  lists, einsum.py:97-106) only where the step ran as a launch of its own.  A step whose result
+ *                  never exists in memory reports 0.0 and the NEXT launched step carries the product of both:
+ *                    - ctn_step_info.kernel == CTN_KERNEL_FUSED (formed inside its consumer);
+ *                    - the first step of a zipper pair run by k_zip_f32 (ctn_exec_step_tile reports (1, 1) for
+ *                      it): (T / s) Y = (T Y) / s, the second step's factor is s_T * s_E' of the reference;
+ *                  the members of a sweep (k_sweep_f32, tile (1, 1) as well) DO report the reference's per-step
+ *                  factors, reconstructed after the launch (within 2e-5 relative, fp32).
  */
 int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space,
                  void* const* outs, int outs_space, double* log_scale, double* step_rescales);
@@ -202,6 +211,10 @@ int ctn_exec_eager_reruns(const ctn_exec* exec);
  * ctn_exec_scales_suspect: the range check ctn_exec_fetch applies (see ctn_exec_set_rescale_mode), on rescale
  *   factors the caller has brought to the host itself; 1 = a lazily rescaled product may have left the dtype's
  *   range (repeat that enqueue and ctn_exec_fetch it), 0 = fine, negative = ctn_status.
+ * ctn_exec_report_suspect: a caller that never fetches (it keeps everything on the device and checks the range itself
+ *   with ctn_exec_scales_suspect) tells the executor the verdict of the run, once per run: consecutive suspect runs
+ *   count like a fetch's own findings, and from the third on the executor stays in eager mode (whose runs are never
+ *   suspect) instead of paying a lazy pass plus the caller's checked repeat every time.  Returns the streak.
  * ctn_exec_combine_split: on the executor's stream, out_packed[0 .. numel) = T_hat (as doubles) and
  *   out_packed[numel] = c of  sum_i t_i e^{c_i}  over n parts; part i is t + i * t_stride elements of `t_dtype`,
  *   its scale c[i * c_stride]; exact zeros are left out of the maximum, the sum is re-stabilised (mean |T_hat| = 1
@@ -209,8 +222,28 @@ int ctn_exec_eager_reruns(const ctn_exec* exec);
  */
 int ctn_exec_snapshot_scales(ctn_exec* exec, double* dev_log_dst, int n, double* host_rescales);
 int ctn_exec_scales_suspect(const ctn_exec* exec, const double* host_rescales, int replicas);
+int ctn_exec_report_suspect(ctn_exec* exec, int suspect);
 int ctn_exec_combine_split(ctn_exec* exec, int t_dtype, const void* t, int64_t t_stride, const double* c,
                            int64_t c_stride, int n, int64_t numel, double* out_packed);
+
+/*
+ * Scale bookkeeping between the STAGES of a sliced contraction (several plans of one caller whose results feed each
+ * other and never leave the device: a lower stage's evaluation is an operand of the stage above, its log-scale
+ * register rides along).  Both run on the executor's stream; all pointers are device pointers unless noted.
+ *
+ * ctn_exec_add_scales: dst[i] = own[i] + sum_j kid_scales[j][kid_index[j][i]], i < n, added in the order of j
+ *   (kid_scales / kid_index: HOST arrays of n_kids device pointers).  dst may be own.
+ * ctn_exec_merge_scales: `n` evaluations of `numel` elements of `t_dtype`, `stride` elements apart (16-byte aligned),
+ *   with registers scales[n], lie on a row-major grid extents[ndim] (ndim <= 8, product n <= 65535); along the axes
+ *   with merged[d] != 0 they are about to be read as ONE strided operand, so every group of evaluations that differ
+ *   only along those axes is multiplied up to its common scale: top = max register among the members that are not
+ *   exact zeros (the whole tensor is looked at), member i *= e^{scales[i] - top}, scales[i] = top (0 for a group of
+ *   zeros; exact zeros are not touched).
+ */
+int ctn_exec_add_scales(ctn_exec* exec, double* dst, const double* own, int n, int n_kids,
+                        const double* const* kid_scales, const int64_t* const* kid_index);
+int ctn_exec_merge_scales(ctn_exec* exec, int t_dtype, void* buf, int64_t stride, int64_t numel, double* scales, int n,
+                          int ndim, const int32_t* extents, const int32_t* merged);
 
 /*
  * Workgroup tile (rows, columns) of the MFMA kernel that the LAST enqueue launched for `step`

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in ctn_abi.h but not exported"
     assert sorted(engine.ABI_SYMBOLS) == declared
-    assert lib.ctn_version() == 4
+    assert lib.ctn_version() == 5
 
 
 def test_library_has_no_torch_dependency():

@@ -42,3 +42,16 @@ def test_bench_line_contract(dtype):
         assert b["unit"] == "inputs/s" and b["value"] > 0 and b["scaling"] == "weak"
         assert b["epilogue_summed_steps"] == 12 - 2 and b["parity_vs_oracle_first_64_inputs"]["ok"] is True
         assert "peps_strong_scaling" in r
+        # ... and the other BASELINE configs (round-3 verdict, item 2): known answers and definition checks inside the line
+        cfgs = r["configs"]
+        for name in ("cfg1", "cfg2", "cfg3b_B1024", "cfg4_i_cp_hyper", "cfg4_ii_tucker_dense_hub",
+                     "cfg4_iii_tucker_delta_hub", "cfg4_iv_cp_wide_r4096"):
+            assert name in cfgs and "error" not in cfgs[name], (name, cfgs.get(name))
+        assert cfgs["cfg1"]["known_answer"]["ok"] is True and cfgs["cfg1"]["device_us_per_contraction"] > 0
+        assert cfgs["cfg2"]["known_answer"]["ok"] is True and cfgs["cfg2"]["known_answer"]["log_scale_hex"] == "0x1.12a72fbccf574p+10"
+        assert cfgs["cfg3b_B1024"]["workload"].endswith("B1024_per_gpu") and cfgs["cfg3b_B1024"]["value"] > 0
+        for name in ("cfg4_i_cp_hyper", "cfg4_ii_tucker_dense_hub", "cfg4_iii_tucker_delta_hub", "cfg4_iv_cp_wide_r4096"):
+            assert cfgs[name]["spot_check_vs_definition_f64"]["ok"] is True and 0 < cfgs[name]["frac_of_mfma_peak"] < 1
+        # the hyperedge route and the materialised delta hub give the same entry (same factor matrices)
+        a, b_ = cfgs["cfg4_i_cp_hyper"]["spot_check_vs_definition_f64"], cfgs["cfg4_iii_tucker_delta_hub"]["spot_check_vs_definition_f64"]
+        assert a["want"] == b_["want"] and abs(a["got"] - b_["got"]) <= 1e-3 * abs(a["want"]) + 1e-9

@@ -1296,6 +1296,68 @@ def test_sweep_steps_aside_in_eager_mode_and_survives_an_eager_repeat(monkeypatc
     E.clear_caches()
 
 
+@pytest.mark.parametrize("batch", [256, 1000])
+def test_sweep_is_not_taken_across_interleaved_chains(batch, monkeypatch):
+    """Two batched MPS hanging on one batch hyperedge, walked ALTERNATELY (a site of chain A, a site of chain B, ...):
+    between two members of either chain lies a launched step of the other, whose result the arena may place where the
+    chain's first input was (released right after its first member).  A sweep launches at its last member's position and
+    reads that input there - so such a run must not be taken (round-3 advice, engine.hip sweep_match).  With CTN_SWEEP=1
+    the value must be the per-site launches' and the oracle's, and no step may report the sweep's tile."""
+    from contractn_amd.paths import ssa_to_linear
+    from contractn_amd.utils import get_symbol
+    from oracle import cpu_ref
+
+    n, bond, phys = 6, 128, 4
+    sym = iter(get_symbol(i) for i in range(200))
+    b = next(sym)
+    terms, shapes = [None] * (4 * n), [None] * (4 * n)
+    for chain in range(2):
+        base = 2 * n * chain
+        left = None
+        for i in range(n):
+            p_, right = next(sym), (next(sym) if i + 1 < n else None)
+            legs = [p_] + ([left] if left else []) + ([right] if right else [])
+            terms[base + i] = "".join(legs)
+            shapes[base + i] = (phys,) + (bond,) * (len(legs) - 1)
+            terms[base + n + i] = b + p_
+            shapes[base + n + i] = (batch, phys)
+            left = right
+    einstr = ",".join(terms) + "->" + b
+    ssa, nxt = [], 4 * n
+    cur = [None, None]
+    for chain in range(2):
+        ssa.append((2 * n * chain, 2 * n * chain + n))
+        cur[chain] = nxt
+        nxt += 1
+    for i in range(1, n):
+        for chain in range(2):
+            base = 2 * n * chain
+            ssa.append((cur[chain], base + i))
+            ssa.append((nxt, base + n + i))
+            cur[chain] = nxt + 1
+            nxt += 2
+    ssa.append((cur[0], cur[1]))
+    path = ssa_to_linear(ssa, 4 * n)
+    rng = np.random.default_rng(31)
+    ops = [(rng.standard_normal(sh) * (0.25 if sh == (batch, phys) else 1.0 / np.sqrt(bond))).astype(np.float32) for sh in shapes]
+    rt, rc = cpu_ref.contract(einstr, *ops, path=path, split_format=True)
+    ref = np.asarray(rt, dtype=np.float64) * np.exp(float(rc))
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CTN_SWEEP", mode)
+        E.clear_caches()
+        bc = E.BatchedContraction(einstr, shapes, np.float32, optimize=path, replicas=1)
+        for _ in range(3):                                   # eager launches, graph capture, replay
+            t, c = bc.run_host([ops])
+        res[mode] = np.asarray(t[0], dtype=np.float64) * np.exp(float(c[0]))
+        assert not any(tl[0] == 16 and tl[1] == bond * phys for tl in bc.executor.step_tiles())
+        bc.executor.close()
+    monkeypatch.delenv("CTN_SWEEP")
+    E.clear_caches()
+    assert np.max(np.abs(res["1"] - ref)) <= 1e-4 * np.max(np.abs(ref))
+    assert np.array_equal(res["0"], res["1"])
+
+
 # ---- a full dot of a tensor with a transposed one (k_dot_tr) -----------------------------------------------------------------
 @pytest.mark.parametrize("einstr,shapes,dtype", [
     ("ab,ba->", [(512, 512), (512, 512)], np.float32),           # the closing dot of a sliced 8 x 8 PEPS (D = 8)
