@@ -32,6 +32,7 @@
 #include "kernels_mfma_g64.h"
 #include "kernels_mfma_h.h"
 #include "kernels_zip.h"
+#include "kernels_zipl.h"
 #include "kernels_sweep.h"
 #include "kernels_mfma_lat.h"
 #include "kernels_stream.h"
@@ -62,6 +63,10 @@ struct DevSwitches {
   int sweep = -1;        // CTN_SWEEP: 0 never walk a chain of epilogue-summed steps in one launch (k_sweep_f32), 1 whenever one matches (tests)
   int dot_tr = 1;        // CTN_DOT_TR=0: full dots against a transposed tensor stay on k_dot_split's 4-byte gathers
   int zip = -1;          // CTN_ZIP: 0 never fuse a zipper's two GEMM steps into one launch (k_zip_f32), 1 whenever the pair matches (tests)
+  int zipl = -1;         // CTN_ZIPL: 0 never run a zipper pair as one latency-form launch (k_zip_lat), 1 whenever the pair matches (tests)
+  int zipl_max_r = 4;    // CTN_ZIPL_MAX_R: most networks in flight for which k_zip_lat is taken by default (100-site D = 256
+                         // network, ms per pass, k_zip_lat / per-step launches: R = 1 1.6 / 2.05, 2: 1.8 / 3.3, 4: 2.4 / 3.5, 8: 4.5 / 4.4)
+  int zipl_mp = 0;       // CTN_ZIPL_MP=32|64: force the part of m1 a k_zip_lat workgroup owns (tests)
   bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
   const char* stamps = nullptr;  // CTN_DEBUG_STAMPS=<file> (make STAMPS=1 builds): dump in-kernel cycle stamps
   int stamp_step = -1;   // CTN_DEBUG_STAMP_STEP=<s>: stamp only this step
@@ -78,6 +83,9 @@ static DevSwitches read_dev_switches() {
   d.lat = num("CTN_LAT", -1);
   d.hform = num("CTN_H", -1);
   d.zip = num("CTN_ZIP", -1);
+  d.zipl = num("CTN_ZIPL", -1);
+  d.zipl_max_r = num("CTN_ZIPL_MAX_R", 4);
+  d.zipl_mp = num("CTN_ZIPL_MP", 0);
   d.dot_tr = num("CTN_DOT_TR", 1);
   d.sweep = num("CTN_SWEEP", -1);
   d.lat64_min_k = num("CTN_LAT64_MIN_K", 512);
@@ -135,6 +143,13 @@ struct Exec {
   struct ZipDesc { bool on = false; int64_t ldE = 0, ldXq = 0, ldXk = 0, ldYq = 0, ldYm = 0, ldC = 0; int Q = 0, U = 0, K1 = 0; };
   std::vector<ZipDesc> zip;
   std::vector<char> zip_skip;
+  // the same pairs in their latency form (kernels_zipl.h): zl[s2] = the fused launch of steps (s2 - 1, s2), whose result
+  // leaves as slabs; from_prev = its E is the slabs of the pair before, feeds_next = the next pair adds its slabs up (else
+  // k_zip_slab_sum does); zl_skip[s1] like zip_skip
+  struct ZipLat { bool on = false, from_prev = false, feeds_next = false; int buf = 0, mp = 32; ZipDesc d; };
+  std::vector<ZipLat> zl;
+  std::vector<char> zl_skip;
+  float* d_zl_slab[2] = {nullptr, nullptr};   // [R][S][U][ZM] each, ping-pong along the chain
   // a sweep (kernels_sweep.h): a run of epilogue-summed GEMM steps, each on the result of the one before, walked by ONE
   // launch at the position of its last member; sweep_role[s] = 1 a member that is never launched, 2 the last member
   struct SweepDesc {
@@ -203,6 +218,8 @@ struct Exec {
   std::vector<LeafGroup> groups;    // per step: len >= 2 at the head of a group, else 0
   StepArgs* h_group_args = nullptr; // pinned: the one-time upload may fall inside a stream capture
   StepArgs* d_group_args = nullptr;
+  bool defer_finish = false;        // ctn_exec_set_finish_mode(1): the final division waits for ctn_exec_finish
+  double* d_mult = nullptr;         // [R] factors of ctn_exec_finish
   char* d_merge = nullptr;          // ctn_exec_merge_scales: liveness flags + new registers, grown on demand
   size_t merge_bytes = 0;
   int timing_slots = 0;             // 0 = timing off
@@ -216,7 +233,7 @@ struct Exec {
                     (void*)d_stepOff, (void*)d_stepSlots,
                     (void*)d_stage_in, (void*)d_stage_out, (void*)d_group_args, (void*)d_sweep_ids, (void*)d_sweep_off,
                     (void*)d_sweep_slots, (void*)d_sweep_a, (void*)d_sweep_s, (void*)d_sweep_z, (void*)d_sweep_la, (void*)d_sweep_ls,
-                    (void*)d_merge})
+                    (void*)d_merge, (void*)d_zl_slab[0], (void*)d_zl_slab[1], (void*)d_mult})
       if (p) (void)hipFree(p);
     if (h_pack) (void)hipHostFree(h_pack);
     if (h_group_args) (void)hipHostFree(h_group_args);
@@ -529,7 +546,7 @@ static void launch_splitk_reduce(Exec* E, int partials, int R, const StepArgs& a
 // Do steps (s2 - 1, s2) form a zipper pair that k_zip_f32 can run as one launch?  Checked on the plan's own offset
 // tables (every operand dense along its innermost index with uniform strides), so nothing about the network's labels
 // is assumed: T = E . X with |m1| = 256 rows from E, columns (q, u) from X; E' = T . Y contracting (m1, q), |n2| = 256.
-static bool zip_match(const Plan& P, int s2, Exec::ZipDesc* z) {
+static bool zip_match(const Plan& P, int s2, Exec::ZipDesc* z, int u_mult = ZU) {
   if (s2 < 1 || s2 + 1 >= P.n_steps || P.dtype != CTN_F32) return false;
   const Step& a = P.steps[s2 - 1];
   const Step& b = P.steps[s2];
@@ -539,7 +556,7 @@ static bool zip_match(const Plan& P, int s2, Exec::ZipDesc* z) {
   };
   if (!plain(a) || !plain(b) || b.lhs != a.out || !b.cvec) return false;
   if (a.rhs >= P.n_inputs || b.rhs >= P.n_inputs) return false;            // X and Y: network inputs (scale 1)
-  if (a.M != ZM || b.N != ZM || a.K % ZK != 0 || a.K < 2 * ZK || a.N % ZU != 0) return false;
+  if (a.M != ZM || b.N != ZM || a.K % ZK != 0 || a.K < 2 * ZK || a.N % u_mult != 0) return false;
   const int32_t* T = P.tables.data();
   const int32_t *omA = T + a.t.omA, *okA = T + a.t.okA, *onB = T + a.t.onB, *okB = T + a.t.okB, *omC = T + a.t.omC, *onC = T + a.t.onC;
   const int64_t N1 = a.N;
@@ -547,7 +564,7 @@ static bool zip_match(const Plan& P, int s2, Exec::ZipDesc* z) {
   for (int64_t n = 0; n < N1; ++n) if (onC[n] != n) return false;
   int64_t U = N1;
   for (int64_t n = 1; n < N1; ++n) if (onB[n] != onB[0] + n) { U = n; break; }
-  if (onB[0] != 0 || U % ZU != 0 || N1 % U != 0) return false;
+  if (onB[0] != 0 || U % u_mult != 0 || N1 % U != 0) return false;
   const int64_t Q = N1 / U, ldXq = Q > 1 ? onB[U] : 0;
   for (int64_t n = 0; n < N1; ++n) if (onB[n] != (n / U) * ldXq + n % U) return false;
   const int64_t ldE = okA[1] - okA[0], ldXk = okB[1] - okB[0];
@@ -788,6 +805,73 @@ static int exec_launch_steps(Exec* E) {
         hipLaunchKernelGGL(k_sweep_finish, dim3((unsigned)sd.J, (unsigned)R), dim3(256), 0, E->stream, f);
       }
       if (timed_w) HIPCHECK(hipEventRecord(E->events[ew + 1], E->stream));
+      continue;
+    }
+    if (!E->zl_skip.empty() && E->zl_skip[s]) {     // first step of a zipper pair in its latency form (k_zip_lat)
+      if ((int)E->launched_tile.size() != P.n_steps) E->launched_tile.assign(P.n_steps, 0);
+      E->launched_tile[s] = (1 << 16) | 1;          // marker: absorbed into the next launched step
+      if (E->timing_runs < E->timing_slots) {
+        const size_t e0 = ((size_t)E->timing_runs * P.n_steps + s) * 2;
+        HIPCHECK(hipEventRecord(E->events[e0], E->stream));
+        HIPCHECK(hipEventRecord(E->events[e0 + 1], E->stream));
+      }
+      continue;
+    }
+    if (!E->zl.empty() && E->zl[s].on) {
+      const Exec::ZipLat& L = E->zl[s];
+      const Exec::ZipDesc& zd = L.d;
+      const Step& s1 = P.steps[s - 1];
+      const int S = ZM / L.mp, nub = zd.U / 16;
+      const bool eager = E->eager_rescale;
+      ZipLatArgs z{};
+      z.ptrs = E->d_ptrs; z.n_tensors = E->n_tensors;
+      z.idE = s1.lhs; z.idX = s1.rhs; z.idY = st.rhs;
+      z.slabs_in = (L.from_prev && !eager) ? E->d_zl_slab[L.buf ^ 1] : nullptr;
+      z.slabs_out = E->d_zl_slab[L.buf];
+      z.ldE = zd.ldE; z.ldXq = zd.ldXq; z.ldXk = zd.ldXk; z.ldYq = zd.ldYq; z.ldYm = zd.ldYm;
+      z.U = zd.U; z.R = R;
+      z.partE = nullptr; z.PE = 0; z.strideE = 0; z.numelE = 1.0;
+      if (s1.lhs >= P.n_inputs && P.stabilize && !eager && P.steps[P.tensors[s1.lhs].producer].kernel != CTN_KERNEL_FUSED) {
+        const int ps = P.tensors[s1.lhs].producer;
+        z.partE = E->d_partials + (size_t)E->step_off[ps] * R;
+        z.PE = z.strideE = E->step_partials[ps];
+        z.numelE = (double)P.tensors[s1.lhs].numel;
+      }
+      z.min_norm = P.min_norm;
+      z.partC = E->d_partials + (size_t)E->step_off[s] * R;
+      z.partC_stride = E->step_partials[s];
+      const bool timed_z = E->timing_runs < E->timing_slots;
+      const size_t ez = timed_z ? ((size_t)E->timing_runs * P.n_steps + s) * 2 : 0;
+      if (timed_z) HIPCHECK(hipEventRecord(E->events[ez], E->stream));
+      if ((int)E->launched_tile.size() != P.n_steps) E->launched_tile.assign(P.n_steps, 0);
+      E->launched_tile[s] = (L.mp << 16) | ZM;      // (m1 part, all n2) per workgroup, 16 values of u
+      const dim3 gz((unsigned)((int64_t)R * nub * S));
+      z.dbg = nullptr;
+      if (E->sw.stamps && (E->sw.stamp_step < 0 || E->sw.stamp_step == s)) {
+        const size_t need = (size_t)gz.x;
+        if (E->dbg_tiles < need) {
+          if (E->d_dbg) (void)hipFree(E->d_dbg);
+          HIPCHECK(hipMalloc((void**)&E->d_dbg, need * 64));
+          E->dbg_tiles = need;
+        }
+        z.dbg = E->d_dbg;
+        HIPCHECK(hipMemsetAsync(E->d_dbg, 0, E->dbg_tiles * 64, E->stream));
+      }
+      if (zd.Q == 4 && L.mp == 32) hipLaunchKernelGGL((k_zip_lat<4, 32>), gz, dim3(512), 0, E->stream, z);
+      else if (zd.Q == 4) hipLaunchKernelGGL((k_zip_lat<4, 64>), gz, dim3(512), 0, E->stream, z);
+      else hipLaunchKernelGGL((k_zip_lat<2, 64>), gz, dim3(512), 0, E->stream, z);
+      if (!L.feeds_next || eager) {                 // nobody adds these slabs up while loading them: do it here
+        hipLaunchKernelGGL(k_zip_slab_sum, dim3((unsigned)E->step_partials[s], (unsigned)R), dim3(256), 0, E->stream,
+                           (const float*)z.slabs_out, S, zd.U, (void* const*)E->d_ptrs, E->n_tensors, st.out, zd.ldC, z.partC,
+                           z.partC_stride);
+        if (eager && P.stabilize && s + 1 < P.n_steps) {
+          const int64_t numel = P.tensors[st.out].numel;
+          const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / 4 + 255) / 256, 2048)), R);
+          hipLaunchKernelGGL(k_renorm<float>, g, dim3(256), 0, E->stream, (void* const*)E->d_ptrs, E->n_tensors, st.out, numel,
+                             (const double*)z.partC, E->step_partials[s], E->step_partials[s], P.min_norm);
+        }
+      }
+      if (timed_z) HIPCHECK(hipEventRecord(E->events[ez + 1], E->stream));
       continue;
     }
     if (!E->zip_skip.empty() && E->zip_skip[s]) {   // first step of a zipper pair: runs inside the next step's launch
@@ -1229,7 +1313,9 @@ static int exec_launch_steps(Exec* E) {
   f.out_numel = P.output().numel;
   f.n_steps = P.n_steps; f.R = R; f.id_out = P.n_inputs + P.n_steps - 1; f.n_tensors = E->n_tensors;
   f.stabilize = P.stabilize ? 1 : 0;
-  int fb = (int)std::min<int64_t>((P.output().numel + 255) / 256, 1024);
+  f.defer = E->defer_finish ? 1 : 0;
+  f.vec = E->outs_aligned16 ? 1 : 0;
+  int fb = (int)std::min<int64_t>((P.output().numel / (f.vec ? (P.dtype == CTN_F64 ? 2 : 4) : 1) + 255) / 256, 4096);
   if (fb < 1) fb = 1;
   const dim3 sg((P.n_steps + 3) / 4, R);
   if (P.dtype == CTN_F32) {
@@ -1541,6 +1627,43 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
       E.zip.clear(); E.zip_skip.clear();
     }
   }
+  // the same pairs in their latency form: a few networks in flight (or CTN_ZIPL=1), and no throughput-form pair taken
+  if (!P.chain && P.dtype == CTN_F32 && E.zip.empty() && E.sw.zipl != 0 && (E.sw.zipl == 1 || replicas <= E.sw.zipl_max_r)) {
+    E.zl.assign(P.n_steps, Exec::ZipLat());
+    E.zl_skip.assign(P.n_steps, 0);
+    bool any = false;
+    int64_t slab_elems = 0;
+    for (int s = 1; s + 1 < P.n_steps; ++s) {
+      Exec::ZipDesc z;
+      if (E.zl_skip[s - 1] || (s >= 2 && E.zl[s - 1].on) || !zip_match(P, s, &z, 16)) continue;
+      if (z.K1 != ZM || (z.Q != 4 && z.Q != 2) || z.ldC % 4 || z.ldE % 4 || z.ldXk % 4 || z.ldXq % 4 || z.ldYm % 4 || z.ldYq % 4) continue;
+      // the part of m1 a workgroup owns: 32 (8 slabs, 128 workgroups per network at |u| = 256) while that still fits ONE
+      // round of workgroups, else 64 (4 slabs, half the workgroups, each with twice the work per byte it loads)
+      int mp = 64;
+      if (z.Q == 4 && (E.sw.zipl_mp == 32 || (E.sw.zipl_mp == 0 && (int64_t)replicas * (z.U / 16) * 8 <= E.n_cu))) mp = 32;
+      const int S = ZM / mp;
+      if ((z.U / 16) * S > kMaxPartials) continue;
+      E.zl[s].on = true; E.zl[s].d = z; E.zl[s].mp = mp;
+      E.zl_skip[s - 1] = 1;
+      any = true;
+      slab_elems = std::max<int64_t>(slab_elems, (int64_t)S * z.U * ZM);
+      E.step_partials[s] = (z.U / 16) * S;        // one abs-sum partial per workgroup (of its slab piece)
+    }
+    if (any) {
+      for (int s = 3; s + 1 < P.n_steps; ++s) {   // links of the chain: the pair (s - 1, s) takes the result of the pair (s - 3, s - 2)
+        if (!E.zl[s].on || !E.zl[s - 2].on || P.steps[s - 1].lhs != P.steps[s - 2].out) continue;
+        if (E.zl[s - 2].d.U != ZM || E.zl[s - 2].mp != E.zl[s].mp || E.zl[s - 2].d.ldC != E.zl[s].d.ldE) continue;
+        E.zl[s].from_prev = true;
+        E.zl[s].buf = E.zl[s - 2].buf ^ 1;
+        E.zl[s - 2].feeds_next = true;
+      }
+      E.part_slots = 0;
+      for (int s = 0; s < P.n_steps; ++s) { E.step_off[s] = E.part_slots; E.part_slots += E.step_partials[s]; }
+      for (int i = 0; i < 2; ++i) HIPCHECK_X(hipMalloc((void**)&E.d_zl_slab[i], (size_t)replicas * slab_elems * 4));
+    } else {
+      E.zl.clear(); E.zl_skip.clear();
+    }
+  }
   // full dots against a transposed tensor
   if (!P.chain && E.sw.dot_tr) {
     E.dot_tr.assign(P.n_steps, Exec::DotTr());
@@ -1726,12 +1849,13 @@ static bool exec_scales_suspect(const Exec* E, const double* resc = nullptr, int
       };
       if (st.kernel == CTN_KERNEL_FUSED) continue;
       if (!E->zip_skip.empty() && E->zip_skip[s]) continue;          // runs inside the next step's launch
+      if (!E->zl_skip.empty() && E->zl_skip[s]) continue;
       if (!E->sweep_role.empty() && E->sweep_role[s] && !E->eager_rescale) {   // a sweep keeps its products in range by itself
         if (!std::isfinite(rs[s])) return true;
         continue;
       }
       double sab = scale_of(st.lhs) * (st.rhs >= 0 ? scale_of(st.rhs) : 1.0) * (st.lhs2 >= 0 ? scale_of(st.lhs2) : 1.0);
-      if (!E->zip.empty() && E->zip[s].on)                           // the fused pair accumulates on E, X and Y as stored
+      if ((!E->zip.empty() && E->zip[s].on) || (!E->zl.empty() && E->zl[s].on))   // the fused pair accumulates on E, X and Y as stored
         sab = scale_of(P.steps[s - 1].lhs) * scale_of(P.steps[s - 1].rhs) * scale_of(st.rhs);
       const double so = rs[s];
       if (!std::isfinite(so) || !std::isfinite(sab)) return true;
@@ -1786,6 +1910,45 @@ int ctn_exec_set_rescale_mode(ctn_exec* exec, int mode) {
 }
 
 int ctn_exec_eager_reruns(const ctn_exec* exec) { return exec ? exec->e.eager_reruns : CTN_INVALID_ARG; }
+
+int ctn_exec_set_finish_mode(ctn_exec* exec, int mode) {
+  if (!exec || mode < 0 || mode > 1) { g_err = "finish mode must be 0 (normalise at the end of every run) or 1 (deferred to ctn_exec_finish)"; return CTN_INVALID_ARG; }
+  Exec* E = &exec->e;
+  const int prev = E->defer_finish ? 1 : 0;
+  if (prev != mode && E->graph_exec) {             // the captured k_finalize carries the old mode
+    DeviceGuard dg(E->device);
+    HIPCHECK(dg.err);
+    HIPCHECK(hipStreamSynchronize(E->stream));
+    (void)hipGraphExecDestroy(E->graph_exec);
+    E->graph_exec = nullptr;
+  }
+  E->defer_finish = mode == 1;
+  return prev;
+}
+
+int ctn_exec_finish(ctn_exec* exec, const double* mult) {
+  if (!exec || !mult) { g_err = "NULL argument"; return CTN_INVALID_ARG; }
+  Exec* E = &exec->e;
+  const Plan& P = *E->plan;
+  if (!E->defer_finish || !E->ptrs_valid) { g_err = "ctn_exec_finish: no deferred run to finish (ctn_exec_set_finish_mode(1), then enqueue)"; return CTN_INVALID_ARG; }
+  DeviceGuard dg(E->device);
+  HIPCHECK(dg.err);
+  if (!E->d_mult) HIPCHECK(hipMalloc((void**)&E->d_mult, (size_t)E->R * 8));
+  HIPCHECK(hipMemcpyAsync(E->d_mult, mult, (size_t)E->R * 8, hipMemcpyHostToDevice, E->stream));
+  const int vec = E->outs_aligned16 ? 1 : 0;
+  const int64_t numel = P.output().numel;
+  const int V = vec ? (P.dtype == CTN_F64 ? 2 : 4) : 1;
+  const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / V + 255) / 256, 4096)), (unsigned)E->R);
+  const int id_out = P.n_inputs + P.n_steps - 1;
+  if (P.dtype == CTN_F32)
+    hipLaunchKernelGGL(k_finish<float>, g, dim3(256), 0, E->stream, (void* const*)E->d_ptrs, E->n_tensors, id_out, numel,
+                       (const double*)E->d_resc, P.n_steps, P.stabilize ? 1 : 0, (const double*)E->d_mult, vec);
+  else
+    hipLaunchKernelGGL(k_finish<double>, g, dim3(256), 0, E->stream, (void* const*)E->d_ptrs, E->n_tensors, id_out, numel,
+                       (const double*)E->d_resc, P.n_steps, P.stabilize ? 1 : 0, (const double*)E->d_mult, vec);
+  HIPCHECK(hipGetLastError());
+  return CTN_OK;
+}
 
 int ctn_exec_run(ctn_exec* exec, const void* const* inputs, int inputs_space, void* const* outs,
                  int outs_space, double* log_scale, double* step_rescales) {

@@ -87,6 +87,8 @@ struct FinalArgs {
   double min_norm;
   int64_t out_numel;
   int32_t n_steps, R, id_out, n_tensors, stabilize;
+  int32_t defer;            // 1: k_finalize leaves the final tensor un-normalised (ctn_exec_finish does it, with the caller's factor)
+  int32_t vec;              // 1: the final buffers are 16-byte aligned: 16-byte accesses
 };
 
 // ---------------------------------------------------------------------------

@@ -489,13 +489,49 @@ __global__ __launch_bounds__(256) void k_finalize(FinalArgs f, const double* __r
     const double tot = block_sum(v, red);
     if (threadIdx.x == 0) f.log_scale[r] = tot;
   }
-  if (!f.stabilize) return;
+  if (!f.stabilize || f.defer) return;
   const double rl = f.rescales[(size_t)r * f.n_steps + f.n_steps - 1];
   if (rl == 0.0) return;  // last step was not rescaled (norm <= min_norm): tensor unchanged
   const T s_last = (T)rl;
   T* out = (T*)f.ptrs[(size_t)r * f.n_tensors + f.id_out];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < f.out_numel; i += (int64_t)gridDim.x * 256)
+  constexpr int V = 16 / (int)sizeof(T);
+  typedef T vecT __attribute__((ext_vector_type(V)));
+  const int64_t nv = f.vec ? f.out_numel / V : 0;            // (a 4 GiB result: one read and one write of it, at full width)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    vecT v = reinterpret_cast<vecT*>(out)[i];
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = v[j] / s_last;
+    reinterpret_cast<vecT*>(out)[i] = v;
+  }
+  for (int64_t i = nv * V + (int64_t)blockIdx.x * 256 + threadIdx.x; i < f.out_numel; i += (int64_t)gridDim.x * 256)
     out[i] = out[i] / s_last;
+}
+
+// k_finish: the deferred form of that division with destabilize() (reference einsum.py:110-114) behind it in the same
+// pass: out = (out / rescale_last) * mult[r], both roundings as the reference's two operations make them - the final
+// tensor is read and written once instead of twice (ctn_exec_set_finish_mode / ctn_exec_finish).
+template <typename T>
+__global__ __launch_bounds__(256) void k_finish(void* const* __restrict__ ptrs, int n_tensors, int id_out, int64_t numel,
+                                                const double* __restrict__ rescales, int n_steps, int stabilize,
+                                                const double* __restrict__ mult, int vec) {
+  const int r = blockIdx.y;
+  const double rl = stabilize ? rescales[(size_t)r * n_steps + n_steps - 1] : 0.0;
+  const bool div = rl != 0.0;
+  const T s_last = div ? (T)rl : (T)1, m = (T)mult[r];
+  T* out = (T*)ptrs[(size_t)r * n_tensors + id_out];
+  constexpr int V = 16 / (int)sizeof(T);
+  typedef T vecT __attribute__((ext_vector_type(V)));
+  const int64_t nv = vec ? numel / V : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    vecT v = reinterpret_cast<vecT*>(out)[i];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { const T q = div ? v[j] / s_last : v[j]; v[j] = q * m; }
+    reinterpret_cast<vecT*>(out)[i] = v;
+  }
+  for (int64_t i = nv * V + (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+    const T q = div ? out[i] / s_last : out[i];
+    out[i] = q * m;
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -339,11 +339,15 @@ def _common_dtype(operands, backend, requested=None):
     return np.dtype(np.float64)  # ints, bools, float64 -> float64
 
 
-def _core_contract(operands, contract_list, backend="numpy", **einsum_kwargs):
+def _core_contract(operands, contract_list, backend="numpy", _plain=False, **einsum_kwargs):
     """Run a contraction list on the GPU; returns ``(rescaled result, log_scale)``.
 
     Same seam as reference einsum.py:326-393: ``contract_list`` is the list of
     5-tuples produced by ``contract_path(..., einsum_call=True)``.
+
+    ``_plain`` (this module's `contract(split_format=False)` only): where the result stays on the device the
+    de-stabilised tensor ``T_hat * exp(log_scale)`` (einsum.py:110-114) is formed in the same pass as the last division
+    by the rescale factor, and ``(tensor, None)`` is returned; everywhere else the flag is ignored.
     """
     operands = list(operands)
     contract_list = tuple(
@@ -355,7 +359,7 @@ def _core_contract(operands, contract_list, backend="numpy", **einsum_kwargs):
         return _core_contract_complex(operands, contract_list, shapes, dtype, backend)
     plan = _native_plan(contract_list, shapes, dtype.name)
     if backend == "torch":
-        return _run_torch(plan, operands, dtype)
+        return _run_torch(plan, operands, dtype, plain=_plain)
     with _locked_executor(plan, 1) as ex:
         outs, _dev_log, resc = ex.run_host([operands])
     log_scale = accumulate_log_scale(resc[0], dtype)
@@ -509,7 +513,7 @@ def _core_contract_complex(operands, contract_list, shapes, dtype, backend):
     return res, log_scale
 
 
-def _run_torch(plan, operands, dtype):
+def _run_torch(plan, operands, dtype, plain=False):
     import torch
 
     tdt = torch.float32 if dtype == np.float32 else torch.float64
@@ -537,10 +541,23 @@ def _run_torch(plan, operands, dtype):
         # it runs on its own non-blocking stream, so wait for the producers of the operands first
         tstream.synchronize()
     with _locked_executor(plan, 1, device=dev.index or 0, stream=stream) as ex:
-        ex.enqueue([o.data_ptr() for o in ops], [out.data_ptr()])
-        _dev_log, resc = ex.fetch()
-    # the torch backend's register: the tensor dtype, sequential adds in it (reference einsum.py:338; App. A)
-    log_scale = accumulate_log_scale(resc[0], dtype, register_dtype=dtype)
+        if plain:
+            ex.set_finish_mode(1)
+        try:
+            ex.enqueue([o.data_ptr() for o in ops], [out.data_ptr()])
+            _dev_log, resc = ex.fetch()
+            # the torch backend's register: the tensor dtype, sequential adds in it (reference einsum.py:338; App. A)
+            log_scale = accumulate_log_scale(resc[0], dtype, register_dtype=dtype)
+            if plain:
+                # destabilize (einsum.py:110-114) in the pass that divides by the last rescale factor: the factor is
+                # exp(register) evaluated in the register's dtype, like `tensor * torch.exp(log_scale)`
+                factor = torch.exp(torch.tensor(float(log_scale), dtype=tdt))
+                ex.finish([float(factor)])
+        finally:
+            if plain:
+                ex.set_finish_mode(0)
+    if plain:
+        return out, None
     return out, torch.tensor(float(log_scale), dtype=tdt, device=dev)
 
 
@@ -584,9 +601,11 @@ def contract(*operands, **kwargs):
     contract_list = _contract_path(
         einstr, shapes, optimize=optimize_arg, memory_limit=memory_limit, use_blas=use_blas
     )
-    result, log_scale = _core_contract(tensors, contract_list, backend, **einsum_kwargs)
+    result, log_scale = _core_contract(tensors, contract_list, backend, _plain=not split_format, **einsum_kwargs)
     if split_format:
         return result, log_scale
+    if log_scale is None:          # (a device-resident result: already de-stabilised, in the pass of its last division)
+        return result
     return destabilize(result, log_scale, backend)
 
 

@@ -40,6 +40,7 @@ ABI_SYMBOLS = (
     "ctn_exec_step_tile", "ctn_exec_set_rescale_mode", "ctn_exec_eager_reruns",
     "ctn_exec_snapshot_scales", "ctn_exec_scales_suspect", "ctn_exec_combine_split",
     "ctn_exec_add_scales", "ctn_exec_merge_scales", "ctn_exec_report_suspect",
+    "ctn_exec_set_finish_mode", "ctn_exec_finish",
 )
 
 
@@ -160,6 +161,8 @@ def load_library():
         "ctn_exec_scales_suspect": (i32, [vp, vp, i32]),
         "ctn_exec_combine_split": (i32, [vp, i32, vp, i64, vp, i64, i32, i64, vp]),
         "ctn_exec_report_suspect": (i32, [vp, i32]),
+        "ctn_exec_set_finish_mode": (i32, [vp, i32]),
+        "ctn_exec_finish": (i32, [vp, C.POINTER(C.c_double)]),
         "ctn_exec_add_scales": (i32, [vp, vp, vp, i32, i32, C.POINTER(vp), C.POINTER(vp)]),
         "ctn_exec_merge_scales": (i32, [vp, i32, vp, i64, i64, vp, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     }
@@ -415,6 +418,17 @@ class Executor:
         """0 = lazy rescale with overflow detection (default), 1 = eager (the reference's order); returns the
         previous mode."""
         return _check(self._lib.ctn_exec_set_rescale_mode(self._h, int(mode)))
+
+    def set_finish_mode(self, mode):
+        """1 = the runs that follow leave the final tensor un-normalised until ``finish`` (include/ctn_abi.h); returns the
+        previous mode."""
+        return _check(self._lib.ctn_exec_set_finish_mode(self._h, int(mode)))
+
+    def finish(self, mult):
+        """Enqueue ``out_r = (out_r / rescale_last_r) * mult[r]`` for a run made in finish mode 1 (after its fetch)."""
+        m = np.ascontiguousarray(np.asarray(mult, dtype=np.float64).reshape(self.replicas))
+        _check(self._lib.ctn_exec_finish(self._h, _ptr(m, C.c_double)))
+        self.synchronize()        # (`m` is read by an asynchronous copy)
 
     def eager_reruns(self):
         """How often a fetch found a lazily rescaled product out of range and repeated the contraction eagerly."""

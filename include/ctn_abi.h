@@ -201,6 +201,19 @@ int ctn_exec_set_rescale_mode(ctn_exec* exec, int mode);
 int ctn_exec_eager_reruns(const ctn_exec* exec);
 
 /*
+ * destabilize() (reference einsum.py:110-114: T_hat * exp(log_scale), what contract(split_format=False) returns) in the
+ * same pass over the final tensor as the last stabilize() division, for results that stay on the device (a 4 GiB
+ * result is then read and written once after its last step, not twice):
+ *   ctn_exec_set_finish_mode(exec, 1): the runs that follow leave the final tensor UN-normalised (registers and
+ *     per-step factors are produced as always); returns the previous mode.  0 restores the default.
+ *   ctn_exec_finish(exec, mult): after ctn_exec_fetch of such a run, on the executor's stream:
+ *     out_r = (out_r / rescale_last_r) * mult[r]  in the tensor dtype, both roundings as the reference's two
+ *     operations make them; mult = host [replicas], normally exp(log_scale) in the register's precision.
+ */
+int ctn_exec_set_finish_mode(ctn_exec* exec, int mode);
+int ctn_exec_finish(ctn_exec* exec, const double* mult);
+
+/*
  * Device-side join of partial results in split format (the index slices of one network run as the
  * replicas of one executor, each producing (T_hat_s, c_s); ranks exchange ONE packed buffer).  The reference has
  * no counterpart (single process); the arithmetic is that of its stabilize(), einsum.py:89-107, applied to a sum.

@@ -135,6 +135,22 @@ def test_torch_device_tensors_zero_copy():
     assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
     out = contract("ab,bc->ac", *g_ops)
     assert float((out.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    # split_format=False on device tensors: de-stabilised in the SAME pass that divides by the last rescale factor
+    # (ctn_exec_finish) - bit for bit `T_hat * exp(c)` with both roundings, dtype and device of the reference's torch backend
+    assert out.is_cuda and out.dtype == torch.float32
+    assert torch.equal(out, t * torch.exp(c.cpu()).to("cuda"))
+    # ... an odd shape (scalar tail of the vector loop), fp64, and the overflow the reference has by design (README.md:73-74)
+    a64 = torch.randn(33, 7, device="cuda", dtype=torch.float64)
+    b64 = torch.randn(7, 13, device="cuda", dtype=torch.float64)
+    t64, c64 = contract("ab,bc->ac", a64, b64, split_format=True)
+    o64 = contract("ab,bc->ac", a64, b64)
+    assert o64.dtype == torch.float64 and torch.equal(o64, t64 * torch.exp(c64.cpu()).to("cuda"))
+    c_op = torch.randn(80, 24, device="cuda")
+    big = contract("ab,bc,cd->ad", g_ops[0] * 1e15, g_ops[1] * 1e15, c_op * 1e15)    # every step in range, exp(register) not
+    assert bool(torch.isinf(big).all())
+    # the split format right after a plain call on the same cached executor: normalised again (mean |T_hat| = 1)
+    t2, c2 = contract("ab,bc->ac", *g_ops, split_format=True)
+    assert torch.equal(t2, t) and float(c2) == float(c)
 
 
 def test_cfg5_device_resident_slicing_zero_copy():

@@ -518,7 +518,8 @@ def test_scale_bookkeeping_kernels_match_numpy():
             cg = cum.reshape(grid)
             top = np.where(live, cg, -np.inf).max(axis=axes, keepdims=True)
             top = np.where(np.isinf(top), 0.0, top)
-            fac = np.exp(cg - top).reshape(n).astype(dtype)
+            with np.errstate(over="ignore"):                # (dead members may sit above their group's top: not used)
+                fac = np.exp(cg - top).reshape(n).astype(dtype)
             want = buf.copy()
             lv = live.reshape(n)
             want[lv] = want[lv] * fac[lv, None]
@@ -529,7 +530,11 @@ def test_scale_bookkeeping_kernels_match_numpy():
             ex.merge_scales(d_buf.data_ptr(), stride, numel, d_cum.data_ptr(), n, grid, [q in axes for q in range(len(grid))], dtype=dtype)
             ex.synchronize()
             assert np.array_equal(d_cum.cpu().numpy(), want_cum)
-            assert np.array_equal(d_buf.cpu().numpy()[:, :numel], want[:, :numel])
+            got = d_buf.cpu().numpy()[:, :numel]
+            # (the device's exp and NumPy's may differ in the last bit of the factor)
+            np.testing.assert_allclose(got, want[:, :numel], rtol=1e-6 if dtype == np.float32 else 1e-14, atol=0)
+            same = ~lv | (fac == 1)                         # exact zeros and the group's top member: not touched at all
+            assert np.array_equal(got[same], buf[same][:, :numel])
     ex.close()
 
 

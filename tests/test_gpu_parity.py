@@ -1156,6 +1156,7 @@ def test_zipper_pairs_in_one_launch_match_the_two_step_path(sites, phys, replica
     rng = np.random.default_rng(5)
     sets = [[(rng.standard_normal(sh) / 16.0).astype(np.float32) for sh in shapes] for _ in range(replicas)]
     res = {}
+    monkeypatch.setenv("CTN_ZIPL", "0")                # (the latency form of the pairs has its own test below)
     for mode in ("0", "1"):
         monkeypatch.setenv("CTN_ZIP", mode)
         E.clear_caches()
@@ -1165,6 +1166,7 @@ def test_zipper_pairs_in_one_launch_match_the_two_step_path(sites, phys, replica
         assert np.array_equal(t, t2) and np.array_equal(c, c2)
         res[mode] = (t, c, bc.executor.step_tiles(), bc.executor.fetch()[1])
         bc.executor.close()
+    monkeypatch.delenv("CTN_ZIPL")
     tiles = res["1"][2]
     pairs = [s for s, tl in enumerate(tiles) if tl == (512, 256)]
     # every interior site but the first (whose E comes out of the opening step with the other leg innermost)
@@ -1177,6 +1179,65 @@ def test_zipper_pairs_in_one_launch_match_the_two_step_path(sites, phys, replica
             assert float(res[mode][0][r]) == float(rt) and abs(float(res[mode][1][r]) - float(rc)) <= 1e-4, (mode, r)
     monkeypatch.delenv("CTN_ZIP")
     E.clear_caches()
+
+
+# ---- zipper pairs in their latency form (k_zip_lat): one launch per site for ONE network in flight ------------------------
+@pytest.mark.parametrize("sites,phys,replicas,mp", [(5, 4, 1, 32), (8, 4, 3, 64), (7, 2, 2, 64), (4, 4, 1, 64), (6, 4, 2, 32)])
+def test_zipper_pairs_latency_form_matches_the_two_step_path(sites, phys, replicas, mp, monkeypatch):
+    """<phi|psi> of two MPS with bond 256 and ONE network (or a few) in flight - what `tn.contract()` itself runs: with
+    CTN_ZIPL=1 every (E . psi_i, T . phi_i) pair is ONE k_zip_lat launch, cut over u AND m1; a pair's partial results leave
+    as 8 (d = 4) or 4 (d = 2) slabs that the next pair adds up while loading them, the last pair's by k_zip_slab_sum.
+    Against the per-step launches (CTN_ZIPL=0) and the oracle; the same bits on every repeat (eager launches, graph
+    capture, replay); the first step of a pair reports rescale 0; the eager rescale mode (every pair followed by slab sum
+    and renorm) and operands 1e9 times larger (the lazy guard) give the oracle's value too."""
+    from contractn_amd import TN
+    from contractn_amd.paths import ssa_to_linear
+    from oracle import cpu_ref
+    from tests import networks as nets
+
+    tn, ssa = nets.mps_overlap(TN, sites, 256, phys, dtype=np.float32, seed=3, scale=16.0)
+    path = ssa_to_linear(ssa, 2 * sites)
+    shapes = [p.shape for p in tn.params]
+    rng = np.random.default_rng(5)
+    sets = [[(rng.standard_normal(sh) / 16.0).astype(np.float32) for sh in shapes] for _ in range(replicas)]
+    res = {}
+    monkeypatch.setenv("CTN_ZIP", "0")
+    monkeypatch.setenv("CTN_ZIPL_MP", str(mp))         # the part of m1 per workgroup: 32 (8 slabs) or 64 (4 slabs)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CTN_ZIPL", mode)
+        E.clear_caches()
+        bc = E.BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=replicas)
+        t, c = bc.run_host(sets)
+        for _ in range(3):                             # graph capture / replay: the same bits
+            t2, c2 = bc.run_host(sets)
+            assert np.array_equal(t, t2) and np.array_equal(c, c2)
+        res[mode] = (t, c, bc.executor.step_tiles(), bc.executor.fetch()[1])
+        if mode == "1":
+            bc.executor.set_rescale_mode(1)            # eager: slab sum + renorm behind every pair, plain E in
+            te, ce = bc.run_host(sets)
+            bc.executor.set_rescale_mode(0)
+            huge = [[(o * np.float32(3e8)).astype(np.float32) for o in ops] for ops in sets]
+            th, ch = bc.run_host(huge)                 # the lazy guard may or may not have to repeat it eagerly
+            t3, c3 = bc.run_host(sets)                 # ... and the next tame operands give the first bits again
+            assert np.array_equal(t3, t) and np.array_equal(c3, c)
+        bc.executor.close()
+    monkeypatch.delenv("CTN_ZIPL")
+    monkeypatch.delenv("CTN_ZIPL_MP")
+    monkeypatch.delenv("CTN_ZIP")
+    E.clear_caches()
+    tiles = res["1"][2]
+    tile = (mp, 256)
+    pairs = [s for s, tl in enumerate(tiles) if tl == tile]
+    assert len(pairs) == sites - 3 and all(tiles[s - 1] == (1, 1) for s in pairs), tiles
+    assert all(res["1"][3][r][s - 1] == 0.0 for s in pairs for r in range(replicas))
+    assert not any(tl in (tile, (1, 1)) for tl in res["0"][2])
+    for r in range(replicas):
+        rt, rc = cpu_ref.contract(tn.einsum_str, *sets[r], path=path, split_format=True)
+        for mode in ("0", "1"):
+            assert float(res[mode][0][r]) == float(rt) and abs(float(res[mode][1][r]) - float(rc)) <= 1e-4, (mode, r)
+        assert float(te[r]) == float(rt) and abs(float(ce[r]) - float(rc)) <= 1e-4
+        ht, hc = cpu_ref.contract(tn.einsum_str, *huge[r], path=path, split_format=True)
+        assert float(th[r]) == float(ht) and abs(float(ch[r]) - float(hc)) <= 1e-3
 
 
 # ---- a batched MPS as ONE launch (k_sweep_f32): 16 inputs per workgroup walk every site of the chain --------------------
