@@ -64,8 +64,9 @@ struct DevSwitches {
   int dot_tr = 1;        // CTN_DOT_TR=0: full dots against a transposed tensor stay on k_dot_split's 4-byte gathers
   int zip = -1;          // CTN_ZIP: 0 never fuse a zipper's two GEMM steps into one launch (k_zip_f32), 1 whenever the pair matches (tests)
   int zipl = -1;         // CTN_ZIPL: 0 never run a zipper pair as one latency-form launch (k_zip_lat), 1 whenever the pair matches (tests)
-  int zipl_max_r = 4;    // CTN_ZIPL_MAX_R: most networks in flight for which k_zip_lat is taken by default (100-site D = 256
-                         // network, ms per pass, k_zip_lat / per-step launches: R = 1 1.6 / 2.05, 2: 1.8 / 3.3, 4: 2.4 / 3.5, 8: 4.5 / 4.4)
+  int zipl_max_r = 8;    // CTN_ZIPL_MAX_R: most networks in flight for which k_zip_lat is taken by default (100-site D = 256
+                         // network, ms per pass, k_zip_lat / per-step launches: R = 1 1.40 / 2.05, 2: 1.58 / 3.3, 4: 2.1 / 3.5,
+                         // 8: 4.1 / 4.4, 16: 8.5 / 7.0)
   int zipl_mp = 0;       // CTN_ZIPL_MP=32|64: force the part of m1 a k_zip_lat workgroup owns (tests)
   bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
   const char* stamps = nullptr;  // CTN_DEBUG_STAMPS=<file> (make STAMPS=1 builds): dump in-kernel cycle stamps
@@ -84,7 +85,7 @@ static DevSwitches read_dev_switches() {
   d.hform = num("CTN_H", -1);
   d.zip = num("CTN_ZIP", -1);
   d.zipl = num("CTN_ZIPL", -1);
-  d.zipl_max_r = num("CTN_ZIPL_MAX_R", 4);
+  d.zipl_max_r = num("CTN_ZIPL_MAX_R", 8);
   d.zipl_mp = num("CTN_ZIPL_MP", 0);
   d.dot_tr = num("CTN_DOT_TR", 1);
   d.sweep = num("CTN_SWEEP", -1);

@@ -25,9 +25,11 @@ namespace ctn {
 // bit-reproducible.  One launch per SITE instead of two per site, 128 workgroups per network (U = 256).
 //
 // Inside the workgroup (8 waves) the pair runs on v_mfma_f32_16x16x4_f32 without any k-loop synchronisation.  Phase 1:
-// a wave owns 16 x 16 blocks (m1 in [16 hh, 16 hh + 16), its q) of T and forms them over ALL of k1 (64 MFMAs per block; E
-// from LDS, where the slab sums were left; X straight from global memory into the operand registers, requested up front).
-// D[i = m1][j = u] leaves lane (u, g) with m1 = 4 g + e in register e: the blocks go to LDS as [block][u][m1], 8 KB in all.
+// a wave owns one q and one PART of k1 and forms all 16 x 16 blocks (m1 in [16 hh, 16 hh + 16)) of T for that q over its
+// part (E from LDS, where the slab sums were left; X straight from global memory into the operand registers, requested up
+// front - no X element is loaded by two waves); the parts of k1 become available one after the other, and a part's waves
+// start while the later rows of E are still arriving.  D[i = m1][j = u] leaves lane (u, g) with m1 = 4 g + e in register
+// e: the blocks go to LDS as [part][block][u][m1], a few KB in all, and are added in the order of the parts when read.
 // Phase 2 cuts the OTHER way: wave w owns the columns n2 in [32 w, 32 w + 32) and sums over every block - its result is
 // complete, nothing is added across waves.  The B operand of a k-step pairs lane group g with m1 = 4 g + e (one 16-byte
 // LDS read per block), and the A operand follows that pairing: Y straight from global memory as 8-byte loads, lane (i, g)
@@ -86,24 +88,27 @@ __device__ __forceinline__ void zl_lds_barrier() {
 
 template <int Q, int MP>
 __global__ __launch_bounds__(512, 1) void k_zip_lat(ZipLatArgs a) {
-  static_assert(8 % Q == 0 && ZM % MP == 0 && ((MP / 16) * Q) % 8 == 0, "blocks of T divide over eight waves, a wave's all of one q");
+  static_assert(8 % Q == 0 && ZM % MP == 0 && MP % 16 == 0, "a wave owns one q and one part of k1");
   constexpr int S = ZM / MP;                   // parts of m1 = slabs of a result
-  constexpr int NBLK = (MP / 16) * Q;          // 16 x 16 blocks of T per workgroup: (hh, q), hh slowest
-  constexpr int NB = NBLK / 8;                 // ... per wave
-  constexpr int WQ = 8 / Q;                    // waves per q
+  constexpr int NBQ = MP / 16;                 // 16 x 16 blocks of T per q: every wave of that q forms all of them ...
+  constexpr int NKP = 8 / Q;                   // ... over ITS part of k1: the waves of a q split the contracted index
+  constexpr int NBLK = NBQ * Q;                // blocks of T per workgroup: (hh, q), hh slowest
   constexpr int LDE = MP + 16;                 // LDS row of the E piece: the four k rows of a fragment read hit different banks
   constexpr int LDT = 20;                      // LDS row of a T block [u][m1 = 0..15]: 16-byte accesses of 16 rows, no bank twice
   constexpr int KS = ZM / 4;                   // k-steps of phase 1 (K1 = ZM)
-  constexpr int NPOS = ZM * (MP / 4) / 512;    // 16-byte pieces of the E piece per thread
+  constexpr int KSW = KS / NKP;                // ... of one wave
+  constexpr int NPOS = ZM * (MP / 4) / 512;    // 16-byte pieces of the E piece per thread; piece p = rows [p, p + 1) * ZM / NPOS
+  constexpr int PP = NPOS / NKP;               // pieces per part of k1
   constexpr int NY0 = NBLK <= 8 ? NBLK : NBLK / 2;   // blocks whose Y fragments are requested before phase 1 (the rest behind it)
+  static_assert(NPOS % NKP == 0 && KS % NKP == 0, "parts of k1 are whole pieces");
   __shared__ __attribute__((aligned(16))) float sE[ZM * LDE];
-  __shared__ __attribute__((aligned(16))) float sT[NBLK * 16 * LDT];
+  __shared__ __attribute__((aligned(16))) float sT[NKP * NBLK * 16 * LDT];
   __shared__ double red[8];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q = w % Q, wq = w / Q;
+  const int q = w % Q, kp = w / Q;
   const int i16 = lane & 15, g = lane >> 4;
   // every XCD a contiguous range of work items; items are ordered (m1 part, replica, u block), so the workgroups of an
   // XCD share their E piece and their rows of Y through its L2
@@ -119,44 +124,37 @@ __global__ __launch_bounds__(512, 1) void k_zip_lat(ZipLatArgs a) {
   ZL_STAMP(0);
 
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
-  const float* __restrict__ X = (const float*)tp[a.idX] + u0;
-  const float* __restrict__ Y = (const float*)tp[a.idY] + (int64_t)(mp * MP) * a.ldYm + 32 * w + 2 * i16;
   const bool from_slabs = a.slabs_in != nullptr;
-  const float* __restrict__ Es = from_slabs ? a.slabs_in + (size_t)r * S * ZM * ZM + mp * MP
-                                            : (const float*)tp[a.idE] + mp * MP;
-  const int64_t ldE = from_slabs ? ZM : a.ldE;
 
   // ---- everything this workgroup reads is requested here, in the order it is needed -----------------------------
-  // (1) the E piece [k1 = 0..255][m1 part], 16 bytes at a time, every slab of it
-  zl_f4 ev[NPOS];
+  // (1) the E piece [k1 = 0..255][m1 part], 16 bytes at a time, every slab of it; piece by piece, so that the rows of
+  // the first part of k1 are complete first.  (The slabs' address is a kernel argument: these requests do not wait for
+  // the pointer table.)
+  zl_f4 sv[NPOS][S];
   if (from_slabs) {
-    zl_f4 sv[S][NPOS];
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-#pragma unroll
-      for (int p = 0; p < NPOS; ++p) {
-        const int f = tid + 512 * p, row = f / (MP / 4), c4 = f % (MP / 4);
-        sv[s][p] = *reinterpret_cast<const zl_f4*>(Es + (size_t)s * ZM * ZM + (int64_t)row * ZM + 4 * c4);
-      }
-#pragma unroll
-    for (int p = 0; p < NPOS; ++p) {
-      ev[p] = sv[0][p];
-#pragma unroll
-      for (int s = 1; s < S; ++s) ev[p] += sv[s][p];             // slab order: fixed
-    }
-  } else {
+    const float* __restrict__ Es = a.slabs_in + (size_t)r * S * ZM * ZM + mp * MP;
 #pragma unroll
     for (int p = 0; p < NPOS; ++p) {
       const int f = tid + 512 * p, row = f / (MP / 4), c4 = f % (MP / 4);
-      ev[p] = *reinterpret_cast<const zl_f4*>(Es + (int64_t)row * ldE + 4 * c4);
+#pragma unroll
+      for (int s = 0; s < S; ++s) sv[p][s] = *reinterpret_cast<const zl_f4*>(Es + (size_t)s * ZM * ZM + (int64_t)row * ZM + 4 * c4);
+    }
+  } else {
+    const float* __restrict__ Es = (const float*)tp[a.idE] + mp * MP;
+#pragma unroll
+    for (int p = 0; p < NPOS; ++p) {
+      const int f = tid + 512 * p, row = f / (MP / 4), c4 = f % (MP / 4);
+      sv[p][0] = *reinterpret_cast<const zl_f4*>(Es + (int64_t)row * a.ldE + 4 * c4);
     }
   }
-  // (2) this wave's X fragments: lane (u = i16, g) holds X[q][k1 = 4 s + g][u0 + u] of k-step s
-  float xb[KS];
+  const float* __restrict__ X = (const float*)tp[a.idX] + u0;
+  const float* __restrict__ Y = (const float*)tp[a.idY] + (int64_t)(mp * MP) * a.ldYm + 32 * w + 2 * i16;
+  // (2) this wave's X fragments: lane (u = i16, g) holds X[q][k1 = 4 s + g][u0 + u] of its k-steps s
+  float xb[KSW];
   {
-    const float* __restrict__ px = X + (int64_t)q * a.ldXq + (int64_t)g * a.ldXk + i16;
+    const float* __restrict__ px = X + (int64_t)q * a.ldXq + (int64_t)(4 * kp * KSW + g) * a.ldXk + i16;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xb[s] = px[(int64_t)(4 * s) * a.ldXk];
+    for (int s = 0; s < KSW; ++s) xb[s] = px[(int64_t)(4 * s) * a.ldXk];
   }
   // (3) E's producer partials (the lazy rescale of the epilogue)
   double pve = 0.0;
@@ -166,14 +164,9 @@ __global__ __launch_bounds__(512, 1) void k_zip_lat(ZipLatArgs a) {
     if (a.PE > 64)
       for (int i = lane + 64; i < a.PE; i += 64) pve += pr[i];
   }
-#pragma unroll
-  for (int p = 0; p < NPOS; ++p) {
-    const int f = tid + 512 * p, row = f / (MP / 4), c4 = f % (MP / 4);
-    *reinterpret_cast<zl_f4*>(sE + row * LDE + 4 * c4) = ev[p];
-  }
   // (4) the Y fragments of phase 2, where this wave owns the columns n2 in [32 w, 32 w + 32) of EVERY block (hh, q'):
   // lane (i, g) takes Y[q'][m1 = 16 hh + 4 g + e][32 w + 2 i, + 1] - row i of the two tiles t = 0, 1, tile t being the
-  // columns 32 w + 2 i + t.  In flight during phase 1 (the second half of them is requested behind it).
+  // columns 32 w + 2 i + t.  Requested behind the first barrier of phase 1 (the second half of them behind phase 1).
   zl_f2 yv[NBLK][4];
   auto yrequest = [&](int blk) {
     const int hh = blk / Q, qq = blk % Q;
@@ -181,29 +174,50 @@ __global__ __launch_bounds__(512, 1) void k_zip_lat(ZipLatArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) yv[blk][e] = *reinterpret_cast<const zl_f2*>(py + (int64_t)e * a.ldYm);
   };
-#pragma unroll
-  for (int blk = 0; blk < NY0; ++blk) yrequest(blk);
   ZL_STAMP(1);
-  zl_lds_barrier();
-  ZL_STAMP(2);
 
-  // ---- phase 1: T_block[m1 = 16 hh + i][u] = sum_k1 E[k1][m1] Xq[k1][u], this wave's NB blocks (one q) -------------
-  zl_f4 acc1[NB];
+  // ---- phase 1: T_block[m1 = 16 hh + i][u] += sum over this wave's k1 of E[k1][m1] Xq[k1][u], all NBQ blocks of its q.
+  // The parts of k1 become available one after the other (slab sums -> LDS -> barrier); the waves of part kp start as soon
+  // as THEIR rows are there, while the later rows are still on their way.
+  zl_f4 acc1[NBQ];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) acc1[b] = zl_f4{0.f, 0.f, 0.f, 0.f};
-  {
-    const float* cA = sE + g * LDE + 16 * (wq * NB) + i16;
+  for (int b = 0; b < NBQ; ++b) acc1[b] = zl_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+  for (int part = 0; part < NKP; ++part) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
-        acc1[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cA[4 * s * LDE + 16 * b], xb[s], acc1[b], 0, 0, 0);
+    for (int pp = 0; pp < PP; ++pp) {
+      const int p = part * PP + pp;
+      const int f = tid + 512 * p, row = f / (MP / 4), c4 = f % (MP / 4);
+      zl_f4 ev = sv[p][0];
+      if (from_slabs) {
+#pragma unroll
+        for (int s = 1; s < S; ++s) ev += sv[p][s];              // slab order: fixed
+      }
+      *reinterpret_cast<zl_f4*>(sE + row * LDE + 4 * c4) = ev;
+    }
+    zl_lds_barrier();
+    if (part == 0) {
+      // the requests for Y go out HERE, behind the first part's barrier: the workgroup's loads are bound by the rate at
+      // which the CU's memory pipeline takes requests (448 KB at ~60 B / clock), not by their latency - issued up front they
+      // held back the first MFMA by 2 k cycles; now they are taken in the shadow of phase 1
+#pragma unroll
+      for (int blk = 0; blk < NY0; ++blk) yrequest(blk);
+    }
+    if (kp == part) {                              // (wave-uniform)
+      const float* cA = sE + (4 * kp * KSW + g) * LDE + i16;
+#pragma unroll
+      for (int s = 0; s < KSW; ++s)
+#pragma unroll
+        for (int b = 0; b < NBQ; ++b)
+          acc1[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cA[4 * s * LDE + 16 * b], xb[s], acc1[b], 0, 0, 0);
+    }
   }
-  // D[i = m1][j = u] leaves lane (u, g) with m1 = 4 g + e in register e: one 16-byte store per block into [blk][u][m1]
+  ZL_STAMP(2);
+  // D[i = m1][j = u] leaves lane (u, g) with m1 = 4 g + e in register e: one 16-byte store per block into [kp][blk][u][m1]
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int blk = (wq * NB + b) * Q + q;
-    *reinterpret_cast<zl_f4*>(sT + (blk * 16 + i16) * LDT + 4 * g) = acc1[b];
+  for (int b = 0; b < NBQ; ++b) {
+    const int blk = b * Q + q;
+    *reinterpret_cast<zl_f4*>(sT + ((kp * NBLK + blk) * 16 + i16) * LDT + 4 * g) = acc1[b];
   }
 #pragma unroll
   for (int blk = NY0; blk < NBLK; ++blk) yrequest(blk);
@@ -212,11 +226,14 @@ __global__ __launch_bounds__(512, 1) void k_zip_lat(ZipLatArgs a) {
   ZL_STAMP(4);
 
   // ---- phase 2: E'^T[n2][u] = sum over the blocks of Y[q'][m1][n2] T[m1][q'][u] for this wave's 32 columns: the B operand
-  // of a k-step pairs lane group g with m1 = 4 g + e - one 16-byte LDS read per block - and Y was requested to match
+  // of a k-step pairs lane group g with m1 = 4 g + e - 16-byte LDS reads, the parts of k1 added in their order - and Y
+  // was requested to match
   zl_f4 acc2[2] = {zl_f4{0.f, 0.f, 0.f, 0.f}, zl_f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int blk = 0; blk < NBLK; ++blk) {
-    const zl_f4 tv = *reinterpret_cast<const zl_f4*>(sT + (blk * 16 + i16) * LDT + 4 * g);
+    zl_f4 tv = *reinterpret_cast<const zl_f4*>(sT + (blk * 16 + i16) * LDT + 4 * g);
+#pragma unroll
+    for (int k2 = 1; k2 < NKP; ++k2) tv += *reinterpret_cast<const zl_f4*>(sT + ((k2 * NBLK + blk) * 16 + i16) * LDT + 4 * g);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll

@@ -205,11 +205,13 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
   // (v (.) x) . A).  Either way the intermediate - 4 GiB for CP with r = n = 1024 - never exists.  fp32 only (the
   // KR loader lives in k_mfma_f32); CTN_FUSE=0 disables, 1 fuses whenever a pattern matches (tests), 2 likewise but
   // without pattern C below (so that pattern B can be tested on the networks C would take).
-  // By default only intermediates of at least 2^28 elements (1 GiB) are fused away: the fused GEMM runs on the
+  // By default only intermediates of at least 2^31 elements (8 GiB in fp32) are fused away: the fused GEMM runs on the
   // register-staged kernel (a direct-to-LDS load cannot multiply), measured 13 % slower than materialising a 4 GiB
-  // product and feeding the large-tile kernel (CP, r = n = 1024: 23.4 vs 20.7 ms) - a trade of time for memory that
-  // only pays when the memory is large; at 2^31 elements it is the only way the step can run at all.
-  constexpr double kFuseMinNumel = 268435456.0;
+  // product and feeding the large-tile kernel (CP, r = n = 1024: 22.5 vs 19.6 ms end to end, round 4; the threshold was
+  // 2^28 elements until then - on a 288 GB part 4 GiB of workspace is not what to save time against); at 2^31 elements a
+  // Khatri-Rao product whose summed label is outermost cannot be addressed by its consumer at all, and fusing is the only
+  // way the step runs (CP-wide, r = 4096).
+  constexpr double kFuseMinNumel = 2147483648.0;
   struct Fuse { int x = -1, y = -1, w = -1; int epw = 0; int32_t pl = -1; };
   std::vector<Fuse> fuse(d.n_steps);
   std::vector<char> absorbed(d.n_steps, 0);
@@ -619,8 +621,13 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     // mostly-masked MFMA tile still beats the streaming kernels by an order of magnitude there
     // ... and so does a huge K against a few rows and columns (8 x 8 x 4,194,304: one mostly-masked 64 x 64 tile
     // per K split streams both operands once - 64 separate dot products re-read them 8 times each)
+    // ... and a long side against only 4 - 7 rows or columns when K is long too (the step that closes an MPS overlap,
+    // 256 x 4 x 256: its 1024 outputs are ONE workgroup of the streaming kernel walking K = 256 a dependent round trip
+    // at a time - 170 us, a tenth of the whole 100-site contraction with one network in flight; a masked 16 x 16 tile per
+    // workgroup with K split over its waves: a few us)
     const bool tileable = st.K >= 8 && ((st.M >= 32 && st.N >= 32) || (st.M >= 128 && st.N >= 8) ||
                                         (st.N >= 128 && st.M >= 8) ||
+                                        (st.K >= 128 && ((st.M >= 128 && st.N >= 4) || (st.N >= 128 && st.M >= 4))) ||
                                         (st.K >= 32768 && st.M >= 4 && st.N >= 4 && st.M * st.N >= 32));
     if (P.dtype == CTN_F32 && tileable) {
       st.kernel = CTN_KERNEL_MFMA_F32;

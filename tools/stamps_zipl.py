@@ -28,6 +28,6 @@ else:
     a = np.fromfile(f, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
     a = a[(a[:, :7] > 0).all(axis=1)]
     med = lambda x: int(np.median(x))
-    names = ["requests+E sum", "barrier", "phase 1 + T to LDS", "barrier", "phase 2", "store"]
+    names = ["requests issued", "E sums + phase 1", "T to LDS", "barrier", "phase 2", "store"]
     print("R", R, "workgroups", len(a), " ".join(f"{n}: {med(a[:, k + 1] - a[:, k])}" for k, n in enumerate(names)),
           "total", med(a[:, 6] - a[:, 0]), "span", a[:, 6].max() - a[:, 0].min(), "(cycles; MFMA ideal per phase 2048 per wave, two waves per SIMD)")
