@@ -514,6 +514,34 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       out.labels = out_labels;
     } else {
       for (int c : {kBatch, kM, kN}) for (auto* l : G[c]) if (!epw || l->label != fuse[s].pl) out.labels.push_back(l->label);
+      // An element-wise product (no label summed: a Khatri-Rao product, always a streaming step, which writes any
+      // label order) of 2^31 elements or more: the step that consumes it can address what it SUMS only through 32-bit
+      // tables, and a label both operands share - the batch group, outermost by default - is exactly what a CP
+      // contraction sums next (`ad,ac->acd` then `acd,ae->cde`, r = 4096: a spans all 2^32 elements).  Order the result
+      // as (labels the consumer keeps)(labels it sums)(the unit-stride label): the kept outer labels then become batch
+      // labels of the consumer (64-bit offsets) and its contracted group spans one small matrix.
+      if (G[kK].empty() && out.labels.size() >= 3) {
+        double out_n = 1.0;
+        for (int32_t lab : out.labels) out_n *= (double)find(lab)->ext;
+        int s2 = -1;
+        for (int q = s + 1; q < d.n_steps && s2 < 0; ++q) if (d.step_lhs[q] == out_id || d.step_rhs[q] == out_id) s2 = q;
+        if (out_n >= 2147483648.0 && s2 >= 0) {
+          int64_t o2 = 0;
+          for (int q = 0; q < s2; ++q) o2 += d.step_out_ndim[q];
+          auto kept = [&](int32_t lab) {
+            for (int a_ = 0; a_ < d.step_out_ndim[s2]; ++a_) if (d.step_out_labels[o2 + a_] == lab) return true;
+            return false;
+          };
+          const int32_t unit = out.labels.back();
+          if (kept(unit)) {
+            std::vector<int32_t> order;
+            for (size_t a_ = 0; a_ + 1 < out.labels.size(); ++a_) if (kept(out.labels[a_])) order.push_back(out.labels[a_]);
+            for (size_t a_ = 0; a_ + 1 < out.labels.size(); ++a_) if (!kept(out.labels[a_])) order.push_back(out.labels[a_]);
+            order.push_back(unit);
+            out.labels = order;
+          }
+        }
+      }
     }
     for (int32_t lab : out.labels) out.dims.push_back(find(lab)->ext);
     out.strides.assign(out.labels.size(), 1);
@@ -647,7 +675,8 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
       const int64_t pad256 = round_up(st.M, 256) * round_up(st.N, kTileN);
       if (!fused && !epw && st.modeA >= 1 && st.modeB >= 1 && st.tileN == kTileN && st.cvec && st.K >= 32 &&
           st.M > kTileM && pad256 * 100 <= pad128 * 115 &&
-          st.rhs >= 0 && P.tensors[st.lhs].numel <= (1LL << 30) && P.tensors[st.rhs].numel <= (1LL << 30)) {  // 32-bit byte offsets
+          st.rhs >= 0 && span_of(G[kM], 0) + span_of(G[kK], 0) < (1LL << 30) &&
+          span_of(G[kN], 1) + span_of(G[kK], 1) < (1LL << 30)) {  // 32-bit byte offsets inside one batch entry's matrices
         st.tileM = 256;
         st.blocks = (int)(st.Bt * ((st.M + kTileM - 1) / kTileM) * ((st.N + st.tileN - 1) / st.tileN));
       }
