@@ -67,6 +67,8 @@ struct DevSwitches {
   int zipl_max_r = 8;    // CTN_ZIPL_MAX_R: most networks in flight for which k_zip_lat is taken by default (100-site D = 256
                          // network, ms per pass, k_zip_lat / per-step launches: R = 1 1.40 / 2.05, 2: 1.58 / 3.3, 4: 2.1 / 3.5,
                          // 8: 4.1 / 4.4, 16: 8.5 / 7.0)
+  int g_big_min_k = 1024;  // CTN_G_BIG_MIN_K: least K from which full long-K steps of any width take the 256 x 256 tiles
+                           // (1536 until round 4; K = 1024, N = 1024: CP r = n = 1024 16.4 -> 15.9 ms, Tucker 15.8 -> 15.7 per mode product)
   int zipl_mp = 0;       // CTN_ZIPL_MP=32|64: force the part of m1 a k_zip_lat workgroup owns (tests)
   bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
   const char* stamps = nullptr;  // CTN_DEBUG_STAMPS=<file> (make STAMPS=1 builds): dump in-kernel cycle stamps
@@ -87,6 +89,7 @@ static DevSwitches read_dev_switches() {
   d.zipl = num("CTN_ZIPL", -1);
   d.zipl_max_r = num("CTN_ZIPL_MAX_R", 8);
   d.zipl_mp = num("CTN_ZIPL_MP", 0);
+  d.g_big_min_k = num("CTN_G_BIG_MIN_K", 1024);
   d.dot_tr = num("CTN_DOT_TR", 1);
   d.sweep = num("CTN_SWEEP", -1);
   d.lat64_min_k = num("CTN_LAT64_MIN_K", 512);
@@ -1089,7 +1092,7 @@ static int exec_launch_steps(Exec* E) {
           // 132.1) are better off with 256 x 128
           // - and so are very long K on any width (K = 2048 ... 8192: +1.5 ... +3 %)
           const bool big = use_g == 1 && !kcontig && st.M % 256 == 0 && st.N % 256 == 0 && st.K % GK == 0 &&
-                           ((st.K >= 512 && st.N <= 512) || st.K >= 1536) && gtiles / 2 >= (int64_t)E->n_cu;
+                           ((st.K >= 512 && st.N <= 512) || st.K >= E->sw.g_big_min_k) && gtiles / 2 >= (int64_t)E->n_cu;
           if (big) {
             used_tile(256, 256);
             a.tiles_n = (int32_t)(st.N / 256);

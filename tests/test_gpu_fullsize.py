@@ -139,28 +139,42 @@ def test_cfg4_cp_hyper_1024_entries_match_the_definition_and_the_delta_hub_netwo
     torch.cuda.empty_cache()
 
 
-def test_cfg4_cp_wide_r4096_runs_without_its_2_to_the_32_element_intermediate():
-    """4(iv) CP-wide r = 4096, n = 1024 (8.8 TFLOP): the Khatri-Rao product `ad,ac->acd` would have 2^32 elements
-    (16 GiB; beyond what any tensor of this engine may hold) - fused into the GEMM as its A operand it never exists.
-    16 entries against the definition in float64."""
+def test_cfg4_cp_wide_r4096_both_ways_match_the_definition(monkeypatch):
+    """4(iv) CP-wide r = 4096, n = 1024 (8.8 TFLOP).  Default (round 4): the Khatri-Rao product `ad,ac->acd` - 2^32
+    elements, 16 GiB - is MATERIALISED, laid out (kept)(summed)(unit-stride) so that the GEMM that sums `a` sees 1024
+    batch entries of a 4096 x 1024 matrix and runs on the large-tile kernel (66.6 ms against 100.7 fused).  CTN_FUSE=1:
+    formed on the fly as the GEMM's A operand, the product never exists.  16 entries against the definition in
+    float64, both ways."""
     import torch
 
     from contractn_amd import einsum as E_
 
     r, n = 4096, 1024
     A, B, C = _mats(3, r, n, seed=9, scale=64.0)
-    clist = E_._contract_path("ac,ad,ae->cde", ((r, n),) * 3, optimize="auto", memory_limit=None, use_blas=True)
-    infos = E_._native_plan(clist, ((r, n),) * 3, "float32").step_infos()
-    assert [i["kernel"] for i in infos] == [5, 2] and infos[1]["mode_a"] >= 3 and infos[1]["k"] == r
-    t, c = contract("ac,ad,ae->cde", A, B, C, split_format=True)
-    scale = float(torch.exp(c.double()))
-    peak = float(t.abs().max()) * scale
     rng = np.random.default_rng(2)
-    for c_, d_, e_ in rng.integers(0, n, size=(16, 3)):
-        ref = float((A[:, c_].double() * B[:, d_].double() * C[:, e_].double()).sum())
-        assert abs(float(t[c_, d_, e_]) * scale - ref) <= 1e-3 * peak
-    del t
-    torch.cuda.empty_cache()
+    picks = rng.integers(0, n, size=(16, 3))
+    for fuse in (None, "1"):
+        if fuse is None:
+            monkeypatch.delenv("CTN_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("CTN_FUSE", fuse)
+        E_.clear_caches()
+        clist = E_._contract_path("ac,ad,ae->cde", ((r, n),) * 3, optimize="auto", memory_limit=None, use_blas=True)
+        infos = E_._native_plan(clist, ((r, n),) * 3, "float32").step_infos()
+        if fuse is None:
+            assert [i["kernel"] for i in infos] == [0, 2] and infos[1]["batch"] == n and infos[1]["k"] == r and infos[1]["tile_m"] == 256
+        else:
+            assert [i["kernel"] for i in infos] == [5, 2] and infos[1]["mode_a"] >= 3 and infos[1]["k"] == r
+        t, c = contract("ac,ad,ae->cde", A, B, C, split_format=True)
+        scale = float(torch.exp(c.double()))
+        peak = float(t.abs().max()) * scale
+        for c_, d_, e_ in picks:
+            ref = float((A[:, c_].double() * B[:, d_].double() * C[:, e_].double()).sum())
+            assert abs(float(t[c_, d_, e_]) * scale - ref) <= 1e-3 * peak
+        del t
+        torch.cuda.empty_cache()
+    monkeypatch.delenv("CTN_FUSE", raising=False)
+    E_.clear_caches()
 
 
 def test_cfg4_tucker_dense_hub_1024_entries_match_the_definition():

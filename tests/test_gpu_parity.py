@@ -888,11 +888,14 @@ def test_fusion_is_off_for_small_intermediates_and_switchable(monkeypatch):
     assert all(i["kernel"] != 5 for i in small)                               # 69k-element product: kept as a step
     mid = _fused_infos("ac,ad,ae->cde", [(1024, 1024), (1024, 1024), (1024, 512)], ((0, 1), (0, 1)))
     assert all(i["kernel"] != 5 for i in mid)                                 # 2^30-element product (4 GiB): materialised (19.6 vs 22.5 ms)
-    big = _fused_infos("ac,ad,ae->cde", [(4096, 1024), (4096, 1024), (4096, 512)], ((0, 1), (0, 1)))
-    assert [i["kernel"] for i in big] == [5, 2]                              # 2^32-element product: fused by default
+    wide = _fused_infos("ac,ad,ae->cde", [(4096, 1024), (4096, 1024), (4096, 1024)], ((0, 1), (0, 1)))
+    assert all(i["kernel"] != 5 for i in wide) and wide[1]["batch"] == 1024   # 2^32-element product: materialised too (66.6 vs 100.7 ms),
+    #                                                                          laid out so that its consumer sums an inner label
+    big = _fused_infos("ac,ad,ae->cde", [(16384, 1024), (16384, 1024), (16384, 512)], ((0, 1), (0, 1)))
+    assert [i["kernel"] for i in big] == [5, 2]                              # 2^34-element product (64 GiB): fused by default
     monkeypatch.setenv("CTN_FUSE", "0")
     E.clear_caches()
-    off = _fused_infos("ac,ad,ae->cde", [(1024, 1024), (1024, 1024), (1024, 512)], ((0, 1), (0, 1)))
+    off = _fused_infos("ac,ad,ae->cde", [(16384, 1024), (16384, 1024), (16384, 512)], ((0, 1), (0, 1)))
     assert all(i["kernel"] != 5 for i in off)
     E.clear_caches()
 
