@@ -1272,6 +1272,8 @@ def kernel_label(key):
     from contractn_amd.engine import KERNEL_NAMES
 
     kind, ma, mb, tm, tn = key
+    if kind == 2 and tm == 512 and tn == 128:
+        return "k_zip64_f32 (two zipper GEMM steps per launch, 64 x 256 outputs per workgroup: the form for 64 ... 127 networks in flight)"
     if kind == 2 and tm == 512:
         return "k_zip_f32 (two zipper GEMM steps per launch: T = E.psi stays in registers, E' = T.phi; 128 x 256 outputs per workgroup)"
     if kind == 2 and tn == 256 and tm in (32, 64):

@@ -32,6 +32,7 @@
 #include "kernels_mfma_g64.h"
 #include "kernels_mfma_h.h"
 #include "kernels_zip.h"
+#include "kernels_zip64.h"
 #include "kernels_zipl.h"
 #include "kernels_sweep.h"
 #include "kernels_mfma_lat.h"
@@ -62,7 +63,8 @@ struct DevSwitches {
   int hform = -1;        // CTN_H: 0 never use the one-tile-per-CU form (k_mfma_f32_h), 1 whenever the shape allows (tests)
   int sweep = -1;        // CTN_SWEEP: 0 never walk a chain of epilogue-summed steps in one launch (k_sweep_f32), 1 whenever one matches (tests)
   int dot_tr = 1;        // CTN_DOT_TR=0: full dots against a transposed tensor stay on k_dot_split's 4-byte gathers
-  int zip = -1;          // CTN_ZIP: 0 never fuse a zipper's two GEMM steps into one launch (k_zip_f32), 1 whenever the pair matches (tests)
+  int zip = -1;          // CTN_ZIP: 0 never fuse a zipper's two GEMM steps into one launch (k_zip_f32), 1 whenever the pair matches
+                         // (tests), 2 likewise with 64 values of u per workgroup (k_zip64_f32)
   int zipl = -1;         // CTN_ZIPL: 0 never run a zipper pair as one latency-form launch (k_zip_lat), 1 whenever the pair matches (tests)
   int zipl_max_r = 8;    // CTN_ZIPL_MAX_R: most networks in flight for which k_zip_lat is taken by default (100-site D = 256
                          // network, ms per pass, k_zip_lat / per-step launches: R = 1 1.40 / 2.05, 2: 1.58 / 3.3, 4: 2.1 / 3.5,
@@ -144,7 +146,8 @@ struct Exec {
   hipGraphExec_t graph_exec = nullptr;
   // zipper pairs (kernels_zip.h): zip[s2] describes the fused launch of steps (s2 - 1, s2); zip_skip[s1] = the first
   // step of such a pair is never launched (its result only exists in the fused kernel's registers)
-  struct ZipDesc { bool on = false; int64_t ldE = 0, ldXq = 0, ldXk = 0, ldYq = 0, ldYm = 0, ldC = 0; int Q = 0, U = 0, K1 = 0; };
+  struct ZipDesc { bool on = false; int64_t ldE = 0, ldXq = 0, ldXk = 0, ldYq = 0, ldYm = 0, ldC = 0; int Q = 0, U = 0, K1 = 0;
+                   int zu = 128; };      // zu: values of u per workgroup (128: k_zip_f32, 64: k_zip64_f32)
   std::vector<ZipDesc> zip;
   std::vector<char> zip_skip;
   // the same pairs in their latency form (kernels_zipl.h): zl[s2] = the fused launch of steps (s2 - 1, s2), whose result
@@ -911,8 +914,8 @@ static int exec_launch_steps(Exec* E) {
       const size_t ez = timed_z ? ((size_t)E->timing_runs * P.n_steps + s) * 2 : 0;
       if (timed_z) HIPCHECK(hipEventRecord(E->events[ez], E->stream));
       if ((int)E->launched_tile.size() != P.n_steps) E->launched_tile.assign(P.n_steps, 0);
-      E->launched_tile[s] = (512 << 16) | 256;      // the fused pair: 128 values of u x all 256 n2 per workgroup
-      const int per = zd.U / ZU;
+      E->launched_tile[s] = (512 << 16) | (zd.zu == 64 ? 128 : 256);   // the fused pair: 128 (or 64) values of u x all 256 n2 per workgroup
+      const int per = zd.U / zd.zu;
       if (E->sw.stamps && (E->sw.stamp_step < 0 || E->sw.stamp_step == s)) {
         const size_t need = (size_t)per * R;
         if (E->dbg_tiles < need) {
@@ -923,7 +926,8 @@ static int exec_launch_steps(Exec* E) {
         z.dbg = E->d_dbg;
         HIPCHECK(hipMemsetAsync(E->d_dbg, 0, E->dbg_tiles * 64, E->stream));
       }
-      hipLaunchKernelGGL(k_zip_f32, dim3((unsigned)((int64_t)per * R)), dim3(512), 0, E->stream, z);
+      if (zd.zu == 64) hipLaunchKernelGGL(k_zip64_f32, dim3((unsigned)((int64_t)per * R)), dim3(512), 0, E->stream, z);
+      else hipLaunchKernelGGL(k_zip_f32, dim3((unsigned)((int64_t)per * R)), dim3(512), 0, E->stream, z);
       if (E->eager_rescale && P.stabilize && s + 1 < P.n_steps) {
         const int64_t numel = P.tensors[st.out].numel;
         const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / 4 + 255) / 256, 2048)), R);
@@ -1613,15 +1617,29 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     bool any = false;
     for (int s = 1; s + 1 < P.n_steps; ++s) {
       Exec::ZipDesc z;
-      if (E.zip_skip[s - 1] || (s >= 2 && E.zip[s - 1].on) || !zip_match(P, s, &z)) continue;
-      if (E.sw.zip != 1 && (int64_t)(z.U / ZU) * replicas < E.n_cu) continue;
-      if (z.U / ZU > kMaxPartials) continue;    // (one abs-sum partial per workgroup: the consumers add at most that many)
+      if (E.zip_skip[s - 1] || (s >= 2 && E.zip[s - 1].on)) continue;
+      // 128 values of u per workgroup (k_zip_f32) when that fills the chip - or CTN_ZIP=1; else 64 (k_zip64_f32) when THAT
+      // does: 64 ... 127 networks of |u| = 256 - or CTN_ZIP=2; fewer networks keep the two-launch / latency forms
+      // ... and of the two the one whose workgroups fill their rounds better (one workgroup per CU and round: 96 networks
+      // are 192 workgroups of 128 - refused - or 384 of 64 - a round and a half: 26.0 ms against 23.0 on the two-launch
+      // forms - while 64 networks are exactly one round of 64: 13.5 ms against 15.9)
+      auto fill = [&](int64_t wgs) { return (double)wgs / (double)(((wgs + E.n_cu - 1) / E.n_cu) * E.n_cu); };
+      Exec::ZipDesc z128, z64;
+      const bool m128 = E.sw.zip != 2 && zip_match(P, s, &z128) && (E.sw.zip == 1 || (int64_t)(z128.U / ZU) * replicas >= E.n_cu);
+      const bool m64 = E.sw.zip != 1 && zip_match(P, s, &z64, Z6U) && z64.K1 % Z6K == 0 &&
+                       (E.sw.zip == 2 || (int64_t)(z64.U / Z6U) * replicas >= E.n_cu);
+      const double f128 = m128 ? fill((int64_t)(z128.U / ZU) * replicas) : 0.0, f64 = m64 ? fill((int64_t)(z64.U / Z6U) * replicas) : 0.0;
+      bool ok = false;
+      if (m128 && (E.sw.zip == 1 || f128 >= 0.9 || f128 >= f64)) { ok = true; z = z128; z.zu = ZU; }
+      else if (m64 && (E.sw.zip == 2 || f64 >= 0.9)) { ok = true; z = z64; z.zu = Z6U; }
+      else if (m128) { ok = true; z = z128; z.zu = ZU; }
+      if (!ok || z.U / z.zu > kMaxPartials) continue;    // (one abs-sum partial per workgroup: the consumers add at most that many)
       E.zip[s] = z;
       E.zip_skip[s - 1] = 1;
       any = true;
       // one abs-sum partial per workgroup of the fused launch; the skipped step keeps its (never written, zero) slots
       E.part_slots -= E.step_partials[s];
-      E.step_partials[s] = z.U / ZU;
+      E.step_partials[s] = z.U / z.zu;
       E.part_slots += E.step_partials[s];
     }
     if (any) {   // regions moved: lay the offsets out again

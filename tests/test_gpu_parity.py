@@ -1144,12 +1144,15 @@ def test_complex_networks_match_the_reference(name):
 
 
 # ---- zipper pairs as one launch (k_zip_f32): the intermediate of two consecutive GEMM steps stays in registers ------------
-@pytest.mark.parametrize("sites,phys,replicas", [(4, 4, 2), (5, 2, 3), (6, 1, 1)])
-def test_zipper_pairs_in_one_launch_match_the_two_step_path(sites, phys, replicas, monkeypatch):
+@pytest.mark.parametrize("sites,phys,replicas,form", [(4, 4, 2, "1"), (5, 2, 3, "1"), (6, 1, 1, "1"),
+                                                      (5, 4, 2, "2"), (4, 2, 3, "2"), (6, 1, 2, "2")])
+def test_zipper_pairs_in_one_launch_match_the_two_step_path(sites, phys, replicas, form, monkeypatch):
     """<phi|psi> of two MPS with bond 256 (the metric's network in small): with CTN_ZIP=1 every (E . psi_i, T . phi_i)
     pair of the zipper runs as ONE k_zip_f32 launch - T only ever exists in accumulators - against the two-launch
     path (CTN_ZIP=0) and the oracle; the first step of a pair reports rescale 0 (its magnitude moves into the second),
-    the log-value is the same; physical dimension 4, 2 and 1 (q = 4, 2, 1 passes over the register-resident T)."""
+    the log-value is the same; physical dimension 4, 2 and 1 (q = 4, 2, 1 passes over the register-resident T).
+    CTN_ZIP=2: the same through k_zip64_f32 (64 values of u per workgroup, four quarters of m1: the form 64 ... 127 networks
+    in flight take by default)."""
     from contractn_amd import TN
     from contractn_amd.paths import ssa_to_linear
     from oracle import cpu_ref
@@ -1162,22 +1165,22 @@ def test_zipper_pairs_in_one_launch_match_the_two_step_path(sites, phys, replica
     sets = [[(rng.standard_normal(sh) / 16.0).astype(np.float32) for sh in shapes] for _ in range(replicas)]
     res = {}
     monkeypatch.setenv("CTN_ZIPL", "0")                # (the latency form of the pairs has its own test below)
-    for mode in ("0", "1"):
+    for mode in ("0", form):
         monkeypatch.setenv("CTN_ZIP", mode)
         E.clear_caches()
         bc = E.BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=replicas)
         t, c = bc.run_host(sets)
         t2, c2 = bc.run_host(sets)                     # graph capture / replay: the same bits
         assert np.array_equal(t, t2) and np.array_equal(c, c2)
-        res[mode] = (t, c, bc.executor.step_tiles(), bc.executor.fetch()[1])
+        res["1" if mode == form else "0"] = (t, c, bc.executor.step_tiles(), bc.executor.fetch()[1])
         bc.executor.close()
     monkeypatch.delenv("CTN_ZIPL")
     tiles = res["1"][2]
-    pairs = [s for s, tl in enumerate(tiles) if tl == (512, 256)]
+    pairs = [s for s, tl in enumerate(tiles) if tl == ((512, 256) if form == "1" else (512, 128))]
     # every interior site but the first (whose E comes out of the opening step with the other leg innermost)
     assert len(pairs) == sites - 3 and all(tiles[s - 1] == (1, 1) for s in pairs), tiles
     assert all(res["1"][3][r][s - 1] == 0.0 for s in pairs for r in range(replicas))          # T is never rescaled
-    assert not any(tl in ((512, 256), (1, 1)) for tl in res["0"][2])
+    assert not any(tl in ((512, 256), (512, 128), (1, 1)) for tl in res["0"][2])
     for r in range(replicas):
         rt, rc = cpu_ref.contract(tn.einsum_str, *sets[r], path=path, split_format=True)
         for mode in ("0", "1"):
