@@ -2,6 +2,8 @@
 // cut over both the free index u AND the contracted index m1, partial results leave as slabs that the next pair adds up
 // while it loads them.  Part of the gfx950 contraction engine (see engine.hip for the overview).
 #pragma once
+#include <type_traits>
+
 #include "kernels_zip.h"
 
 namespace ctn {
@@ -86,6 +88,9 @@ __device__ __forceinline__ void zl_lds_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// (A form for two co-resident workgroups per CU - at most 128 registers, the slabs of a part of k1 requested only when the
+// part before has been written, Y behind phase 1 - was measured for 3 ... 16 networks, LAB_NOTES R4.2: 116 bytes of scratch and
+// late requests made it 2.3 x SLOWER than one workgroup per CU with everything in flight.)
 template <int Q, int MP>
 __global__ __launch_bounds__(512, 1) void k_zip_lat(ZipLatArgs a) {
   static_assert(8 % Q == 0 && ZM % MP == 0 && MP % 16 == 0, "a wave owns one q and one part of k1");
@@ -131,22 +136,24 @@ __global__ __launch_bounds__(512, 1) void k_zip_lat(ZipLatArgs a) {
   // the first part of k1 are complete first.  (The slabs' address is a kernel argument: these requests do not wait for
   // the pointer table.)
   zl_f4 sv[NPOS][S];
-  if (from_slabs) {
-    const float* __restrict__ Es = a.slabs_in + (size_t)r * S * ZM * ZM + mp * MP;
-#pragma unroll
-    for (int p = 0; p < NPOS; ++p) {
-      const int f = tid + 512 * p, row = f / (MP / 4), c4 = f % (MP / 4);
-#pragma unroll
-      for (int s = 0; s < S; ++s) sv[p][s] = *reinterpret_cast<const zl_f4*>(Es + (size_t)s * ZM * ZM + (int64_t)row * ZM + 4 * c4);
-    }
-  } else {
-    const float* __restrict__ Es = (const float*)tp[a.idE] + mp * MP;
-#pragma unroll
-    for (int p = 0; p < NPOS; ++p) {
-      const int f = tid + 512 * p, row = f / (MP / 4), c4 = f % (MP / 4);
-      sv[p][0] = *reinterpret_cast<const zl_f4*>(Es + (int64_t)row * a.ldE + 4 * c4);
-    }
-  }
+#define ZL_EREQUEST(P0, NP)                                                                                              \
+  do {                                                                                                                    \
+    if (from_slabs) {                                                                                                     \
+      const float* __restrict__ Es_ = a.slabs_in + (size_t)r * S * ZM * ZM + mp * MP;                                     \
+      _Pragma("unroll") for (int p = 0; p < (NP); ++p) {                                                                  \
+        const int f = tid + 512 * ((P0) + p), row = f / (MP / 4), c4 = f % (MP / 4);                                      \
+        _Pragma("unroll") for (int s_ = 0; s_ < S; ++s_)                                                                  \
+          sv[p][s_] = *reinterpret_cast<const zl_f4*>(Es_ + (size_t)s_ * ZM * ZM + (int64_t)row * ZM + 4 * c4);           \
+      }                                                                                                                   \
+    } else {                                                                                                              \
+      const float* __restrict__ Es_ = (const float*)tp[a.idE] + mp * MP;                                                  \
+      _Pragma("unroll") for (int p = 0; p < (NP); ++p) {                                                                  \
+        const int f = tid + 512 * ((P0) + p), row = f / (MP / 4), c4 = f % (MP / 4);                                      \
+        sv[p][0] = *reinterpret_cast<const zl_f4*>(Es_ + (int64_t)row * a.ldE + 4 * c4);                                  \
+      }                                                                                                                   \
+    }                                                                                                                     \
+  } while (0)
+  ZL_EREQUEST(0, NPOS);                            // (the slabs of pieces P0 .. P0 + NP - 1 into sv[0 .. NP))
   const float* __restrict__ X = (const float*)tp[a.idX] + u0;
   const float* __restrict__ Y = (const float*)tp[a.idY] + (int64_t)(mp * MP) * a.ldYm + 32 * w + 2 * i16;
   // (2) this wave's X fragments: lane (u = i16, g) holds X[q][k1 = 4 s + g][u0 + u] of its k-steps s
@@ -267,6 +274,7 @@ __global__ __launch_bounds__(512, 1) void k_zip_lat(ZipLatArgs a) {
     a.partC[(size_t)r * a.partC_stride + mp * nub + ub] = tot;
   }
   ZL_STAMP(6);
+#undef ZL_EREQUEST
 }
 
 // The slabs of the LAST pair of a run (or of every pair, in the eager rescale mode) added up into the step's ordinary

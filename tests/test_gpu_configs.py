@@ -29,7 +29,7 @@ def test_cfg3a_mps_overlap_bond256_vs_oracle():
     infos = E._native_plan(E._contract_path(tn.einsum_str, tuple(p.shape for p in tn.params), optimize=path,
                                             memory_limit=None, use_blas=True),
                            tuple(p.shape for p in tn.params), "float32").step_infos()
-    assert sum(i["kernel"] == 2 for i in infos) == 20  # all bulk steps are MFMA GEMMs
+    assert sum(i["kernel"] == 2 for i in infos) == 21  # all bulk steps are MFMA GEMMs, and the closing 256 x 4 x 256 step a masked tile
 
 
 def test_cfg3a_linearity_of_the_log_register():
