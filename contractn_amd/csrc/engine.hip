@@ -71,6 +71,7 @@ struct DevSwitches {
                          // 8: 4.1 / 4.4, 16: 8.5 / 7.0)
   int g_big_min_k = 1024;  // CTN_G_BIG_MIN_K: least K from which full long-K steps of any width take the 256 x 256 tiles
                            // (1536 until round 4; K = 1024, N = 1024: CP r = n = 1024 16.4 -> 15.9 ms, Tucker 15.8 -> 15.7 per mode product)
+  int g_splitk = 1;      // CTN_G_SPLITK=0: no K split over workgroups on the large-tile kernel
   int zipl_mp = 0;       // CTN_ZIPL_MP=32|64: force the part of m1 a k_zip_lat workgroup owns (tests)
   bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
   const char* stamps = nullptr;  // CTN_DEBUG_STAMPS=<file> (make STAMPS=1 builds): dump in-kernel cycle stamps
@@ -91,6 +92,7 @@ static DevSwitches read_dev_switches() {
   d.zipl = num("CTN_ZIPL", -1);
   d.zipl_max_r = num("CTN_ZIPL_MAX_R", 8);
   d.zipl_mp = num("CTN_ZIPL_MP", 0);
+  d.g_splitk = num("CTN_G_SPLITK", 1);
   d.g_big_min_k = num("CTN_G_BIG_MIN_K", 1024);
   d.dot_tr = num("CTN_DOT_TR", 1);
   d.sweep = num("CTN_SWEEP", -1);
@@ -430,6 +432,22 @@ static bool g_launch(const Step& st, int R, int n_cu, int use_g) {
   // replicas = 192 tiles 25.2 against 23.1; 112 = 224 tiles 28.4 against 29.7, 128 = 256 tiles 29.0 against 29.1)
   const int64_t rounds = (gtiles + n_cu - 1) / n_cu;
   return st.K >= 1024 && 4 * gtiles >= 3LL * n_cu && 100 * gtiles >= 85 * rounds * n_cu;
+}
+
+// K split over workgroups ON the large-tile LDS-DMA kernel (256 x 128 tiles; k_mfma_f32_g with a.ks_S > 0, then the
+// fixed-order reduce pass): a planner-eligible step whose tiles cannot fill the chip by themselves while K is long - the
+// root GEMMs of a sliced 2D grid with a rank's few slices in flight (8 x (512 x 512 x 4096): 64 tiles; they ran as 512
+// register-staged 64 x 64 tiles), a batch of 256 x 256 x 2^20 products.  Returns the number of splits (0 = not taken): about
+// two workgroups per CU, every split at least 256 deep and a whole number of 16-deep k-tiles.
+static int g_splitk(const Step& st, int R, int n_cu, int use_g, const DevSwitches& sw, bool c_vec) {
+  if (!use_g || sw.g_splitk == 0 || st.kernel != CTN_KERNEL_MFMA_F32 || st.tileM != 256 || !c_vec || st.collapse || st.rhs < 0) return 0;
+  if (st.K < 2048 || st.K % GK != 0) return 0;
+  const int64_t gtiles = st.Bt * ((st.M + GM - 1) / GM) * ((st.N + st.tileN - 1) / st.tileN) * R;
+  if (gtiles >= n_cu) return 0;
+  int64_t S = (2LL * n_cu + gtiles - 1) / gtiles;
+  S = std::min<int64_t>(std::min<int64_t>(S, 16), st.K / 256);   // (at most 16 slabs: one reduce pass, no folding)
+  while (S > 1 && (st.K % S != 0 || (st.K / S) % GK != 0)) --S;
+  return S >= 2 ? (int)S : 0;
 }
 
 static void plain_tiles(const Step& st, int R, int n_cu, int use_g, bool is_last, int* tm, int* tn, int halve = 1) {
@@ -1005,6 +1023,34 @@ static int exec_launch_steps(Exec* E) {
       case CTN_KERNEL_MFMA_F32: {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
+        if (const int S = (E->d_slab && s + 1 < P.n_steps) ? g_splitk(st, R, E->n_cu, E->mfma_g, E->sw, st.cvec) : 0) {
+          SplitKArgs sk{};
+          sk.slab = E->d_slab;
+          sk.numelC = P.tensors[st.out].numel;
+          sk.S = S;
+          sk.kchunk = (int32_t)(st.K / S);
+          a.ks_slab = sk.slab; a.ks_numelC = sk.numelC; a.ks_S = S; a.ks_chunk = sk.kchunk;
+          a.tiles_m = (int32_t)((st.M + GM - 1) / GM);
+          a.tiles_n = (int32_t)((st.N + st.tileN - 1) / st.tileN);
+          a.blocks_per_replica = (int32_t)(st.Bt * a.tiles_m * a.tiles_n * S);
+          used_tile(256, 128);
+          const dim3 gg((unsigned)((int64_t)a.blocks_per_replica * R));
+          const bool use_asm = !E->sw.g_no_asm;          // (every split is whole k-tiles)
+#define CTN_G_LAUNCH(AA, BB)                                                                             \
+          do {                                                                                           \
+            if (use_asm) hipLaunchKernelGGL((k_mfma_f32_g<4, 2, true, AA, BB>), gg, dim3(256), 0, E->stream, a); \
+            else hipLaunchKernelGGL((k_mfma_f32_g<4, 2, false, AA, BB>), gg, dim3(256), 0, E->stream, a);        \
+          } while (0)
+          if (st.modeA == 2 && st.modeB == 1) CTN_G_LAUNCH(2, 1);
+          else if (st.modeA == 1 && st.modeB == 2) CTN_G_LAUNCH(1, 2);
+          else if (st.modeA == 2 || st.modeB == 2) CTN_G_LAUNCH(2, 2);
+          else CTN_G_LAUNCH(1, 1);
+#undef CTN_G_LAUNCH
+          a.ks_slab = nullptr; a.ks_S = 0;
+          a.partC = part_dst; a.partC_stride = part_stride; reduced = true;
+          launch_splitk_reduce<float>(E, E->step_partials[s], R, a, sk);
+          break;
+        }
         if (const int T = lat_form(st, R, E->n_cu, P.dtype, E->sw)) {
           a.tiles_m = (int32_t)((st.M + T - 1) / T);
           a.tiles_n = (int32_t)((st.N + T - 1) / T);
@@ -1566,6 +1612,8 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
   {
     size_t slab_elems = 0;   // split-K scratch: S slabs shaped like the step's output, per replica
     auto splits_of = [&](const Step& st) {
+      if (P.dtype == CTN_F32)
+        if (const int S = g_splitk(st, replicas, E.n_cu, E.mfma_g, E.sw, st.cvec)) return S;
       if (lat_form(st, replicas, E.n_cu, P.dtype, E.sw)) return 0;
       if (const int S = splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw)) return S;
       if (const int S = dot_splits(st)) return S;
@@ -1592,7 +1640,9 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     const Step& st = P.steps[s];
     E.step_partials[s] = std::max(st.partials, 1);
     if (P.chain) { E.step_off[s] = E.part_slots++; continue; }   // the chain walker: one slot per step, whatever the kernel kind
-    if (const int T = lat_form(st, replicas, E.n_cu, P.dtype, E.sw))
+    if (E.d_slab && P.dtype == CTN_F32 && s + 1 < P.n_steps && g_splitk(st, replicas, E.n_cu, E.mfma_g, E.sw, st.cvec))
+      E.step_partials[s] = (int)std::max<int64_t>(1, std::min<int64_t>(kWaveOutputs, P.tensors[st.out].numel / 1024));
+    else if (const int T = lat_form(st, replicas, E.n_cu, P.dtype, E.sw))
       E.step_partials[s] = (int)(st.Bt * ((st.M + T - 1) / T) * ((st.N + T - 1) / T));
     else if (E.d_slab && (splitk_splits(st, replicas, E.n_cu, P.dtype, E.sw) || dot_splits(st) || stream_splits(st, replicas, E.n_cu) ||
                           rowdot_splits(st, replicas, E.n_cu)))

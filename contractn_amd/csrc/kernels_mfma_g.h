@@ -70,9 +70,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
   const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  const int r = pid / a.blocks_per_replica;       // here: 256 x TNB tiles per replica
-  const int t = pid - r * a.blocks_per_replica;
+  const int r = pid / a.blocks_per_replica;       // here: 256 x TNB tiles per replica (x K splits)
+  int t = pid - r * a.blocks_per_replica;
   const int tiles_mn = a.tiles_m * a.tiles_n;
+  // K split over workgroups (a.ks_S > 0; the launcher takes it when the step's tiles alone cannot fill the chip and K is
+  // long): this workgroup multiplies k in [kbeg, kbeg + Kloc) and leaves its un-scaled tile in slab `sp`, shaped like C;
+  // k_splitk_reduce adds the slabs in a fixed order, rescales, stores and writes the abs-sum partials
+  const bool split = a.ks_S > 0;
+  int sp = 0;
+  if (split) { sp = t / (a.Bt * tiles_mn); t -= sp * (a.Bt * tiles_mn); }
+  const int kbeg = sp * a.ks_chunk;
+  const int Kloc = split ? min(a.K - kbeg, a.ks_chunk) : a.K;
   const int b = t / tiles_mn;
   const int tt = t - b * tiles_mn;
   const int tm = tt / a.tiles_n, tn = tt % a.tiles_n;
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
   const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[b];
   const float* __restrict__ B = (const float*)tp[a.idB] + a.obB[b];
-  float* __restrict__ C = (float*)tp[a.idC] + a.obC[b];
+  float* __restrict__ C = (split ? (float*)a.ks_slab + ((size_t)r * a.ks_S + sp) * a.ks_numelC : (float*)tp[a.idC]) + a.obC[b];
 
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = (w / WNC) * 128, wn = (w % WNC) * (32 * NJ);
@@ -116,13 +124,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   const char* const Bc = reinterpret_cast<const char*>(B);
   // k-offset table entries: scalar loads through the constant address space (measured: fetching them
   // with wave-uniform vector loads next to the LDS-DMA requests costs 2.5 % on the headline)
-  const_i32_ptr okA = (const_i32_ptr)(a.okA + RPW * w);
-  const_i32_ptr okB = (const_i32_ptr)(a.okB + RPW * w);
-  const int nkt = (a.K + GK - 1) / GK;
+  const_i32_ptr okA = (const_i32_ptr)(a.okA + kbeg + RPW * w);
+  const_i32_ptr okB = (const_i32_ptr)(a.okB + kbeg + RPW * w);
+  const int nkt = (Kloc + GK - 1) / GK;
   // ragged K: LDS-DMA cannot mask, so the last k-tile's rows beyond K hold in-bounds garbage (padded
   // k-tables); they are zeroed when read into fragments - both operands, so nothing can turn into NaN
-  const bool ktail = (a.K % GK) != 0;
-  const int krem = a.K - (nkt - 1) * GK;
+  const bool ktail = (Kloc % GK) != 0;
+  const int krem = Kloc - (nkt - 1) * GK;
 
   int ka[RPW], kb[RPW];  // k-offset table entries of the next k-tile to request (wave-uniform)
 #pragma unroll
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
   const float nA = (float)pva, nB = (float)pvb;  // exactly producer_scale<float>()
   const float scA = (a.partA && nA > (float)a.min_norm) ? nA / (float)a.numelA : 1.f;
   const float scB = (a.partB && nB > (float)a.min_norm) ? nB / (float)a.numelB : 1.f;
-  const float iA = 1.0f / scA, iB = 1.0f / scB;
+  const float iA = split ? 1.0f : 1.0f / scA, iB = split ? 1.0f : 1.0f / scB;   // (x * 1 == x: a slab holds the raw sums)
   float asum = 0.f;
   const bool full = (m0 + GM <= a.M) && (n0 + TNB <= a.N);
   auto store_tile = [&](auto full_tag) {
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NJ == 2) ? 2 : 1) void k_mfma_
 #ifdef CTN_STAMPS
   if (a.dbg && tid == 0) a.dbg[(size_t)pid * 8 + 3] = __builtin_amdgcn_s_memtime();
 #endif
-  if (tid == 0) {  // this tile covers up to 2 x (TNB / 128) of the planner's 128 x 128 partial slots
+  if (tid == 0 && !split) {  // this tile covers up to 2 x (TNB / 128) of the planner's 128 x 128 partial slots
     const int tm128 = (a.M + 127) / 128, tn128 = (a.N + 127) / 128;
     double* pc = a.partC + (size_t)r * a.partC_stride + (size_t)b * tm128 * tn128;
 #pragma unroll

@@ -205,13 +205,13 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
   // (v (.) x) . A).  Either way the intermediate - 4 GiB for CP with r = n = 1024 - never exists.  fp32 only (the
   // KR loader lives in k_mfma_f32); CTN_FUSE=0 disables, 1 fuses whenever a pattern matches (tests), 2 likewise but
   // without pattern C below (so that pattern B can be tested on the networks C would take).
-  // By default only intermediates of at least 2^34 elements (64 GiB in fp32) are fused away: the fused GEMM runs on the
+  // By default only intermediates of at least 2^33 elements (32 GiB in fp32; what a streaming step can still write) are fused away: the fused GEMM runs on the
   // register-staged kernel (a direct-to-LDS load cannot multiply) at 0.57 - 0.68 of the MFMA peak, where materialising
   // the product and feeding the large-tile kernel reaches 0.85 - 0.92 - CP, r = n = 1024: 22.5 vs 19.6 ms end to end;
   // CP-wide, r = 4096 (a 16 GiB product): 100.7 vs 66.6 ms (round 4; the threshold was 2^28 elements until then).  On a
   // 288 GB part workspace of that size is not what to save time against; beyond it fusing trades time for memory.
   // (A product of 2^31 elements and more is laid out for its consumer - the labels it sums NOT outermost, see below.)
-  constexpr double kFuseMinNumel = 17179869184.0;
+  constexpr double kFuseMinNumel = 8589934592.0;
   struct Fuse { int x = -1, y = -1, w = -1; int epw = 0; int32_t pl = -1; };
   std::vector<Fuse> fuse(d.n_steps);
   std::vector<char> absorbed(d.n_steps, 0);

@@ -891,12 +891,17 @@ def test_fusion_is_off_for_small_intermediates_and_switchable(monkeypatch):
     wide = _fused_infos("ac,ad,ae->cde", [(4096, 1024), (4096, 1024), (4096, 1024)], ((0, 1), (0, 1)))
     assert all(i["kernel"] != 5 for i in wide) and wide[1]["batch"] == 1024   # 2^32-element product: materialised too (66.6 vs 100.7 ms),
     #                                                                          laid out so that its consumer sums an inner label
-    big = _fused_infos("ac,ad,ae->cde", [(16384, 1024), (16384, 1024), (16384, 512)], ((0, 1), (0, 1)))
-    assert [i["kernel"] for i in big] == [5, 2]                              # 2^34-element product (64 GiB): fused by default
+    big = _fused_infos("ac,ad,ae->cde", [(8192, 1024), (8192, 1024), (8192, 512)], ((0, 1), (0, 1)))
+    assert [i["kernel"] for i in big] == [5, 2]                              # 2^33-element product (32 GiB): fused by default
     monkeypatch.setenv("CTN_FUSE", "0")
     E.clear_caches()
-    off = _fused_infos("ac,ad,ae->cde", [(16384, 1024), (16384, 1024), (16384, 512)], ((0, 1), (0, 1)))
+    off = _fused_infos("ac,ad,ae->cde", [(1024, 1024), (1024, 1024), (1024, 512)], ((0, 1), (0, 1)))
     assert all(i["kernel"] != 5 for i in off)
+    monkeypatch.setenv("CTN_FUSE", "1")
+    E.clear_caches()
+    on = _fused_infos("ac,ad,ae->cde", [(1024, 1024), (1024, 1024), (1024, 512)], ((0, 1), (0, 1)))
+    assert [i["kernel"] for i in on] == [5, 2]
+    monkeypatch.delenv("CTN_FUSE")
     E.clear_caches()
 
 
@@ -1246,6 +1251,94 @@ def test_zipper_pairs_latency_form_matches_the_two_step_path(sites, phys, replic
         assert float(te[r]) == float(rt) and abs(float(ce[r]) - float(rc)) <= 1e-4
         ht, hc = cpu_ref.contract(tn.einsum_str, *huge[r], path=path, split_format=True)
         assert float(th[r]) == float(ht) and abs(float(ch[r]) - float(hc)) <= 1e-3
+
+
+@pytest.mark.parametrize("einstr,shapes", [
+    ("ab,bc,cd->ad", [(512, 4096), (4096, 512), (512, 8)]),        # A k-contiguous, B row-contiguous: <4,2,asm,2,1>
+    ("ba,bc,cd->ad", [(2048, 500), (2048, 384), (384, 8)]),        # both row-contiguous, ragged M: <4,2,asm,1,1>
+    ("ab,cb,cd->ad", [(256, 8192), (256, 8192), (256, 4)]),        # both k-contiguous, one tile, 16 slabs: <4,2,asm,2,2>
+    ("xab,xbc,xcd->xad", [(3, 256, 4096), (3, 4096, 256), (3, 256, 8)]),   # a batch label
+])
+def test_large_tile_kernel_with_k_split_over_workgroups(einstr, shapes, monkeypatch):
+    """A GEMM step whose 256 x 128 tiles cannot fill the chip while K is long (the root GEMMs of a sliced 2D grid with a
+    rank's few slices in flight): K split over workgroups ON the large-tile LDS-DMA kernel, slabs added by the fixed-order
+    reduce pass - against NumPy and against the same plan without the split (CTN_G_SPLITK=0), two replicas, twice for
+    bit-identity."""
+    rng = np.random.default_rng(17)
+    ops = [(rng.standard_normal(s) / np.sqrt(s[-1])).astype(np.float32) for s in shapes]
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops], optimize=[(0, 1), (0, 1)])
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CTN_G_SPLITK", mode)
+        E.clear_caches()
+        bc = E.BatchedContraction(einstr, shapes, np.float32, optimize=((0, 1), (0, 1)), replicas=2)
+        t, c = bc.run_host([ops, [2 * o for o in ops]])
+        t2, c2 = bc.run_host([ops, [2 * o for o in ops]])
+        assert np.array_equal(t, t2) and np.array_equal(c, c2)
+        res[mode] = (t, c, bc.executor.step_tiles(), bc.plan.step_infos())
+        bc.executor.close()
+    monkeypatch.delenv("CTN_G_SPLITK")
+    E.clear_caches()
+    assert res["1"][2][0] == (256, 128) and res["1"][3][0]["tile_m"] == 256, (res["1"][2], res["1"][3][0])
+    assert res["0"][2][0] != (256, 128)
+    for mode in ("1", "0"):
+        got = res[mode][0][0].astype(np.float64) * np.exp(float(res[mode][1][0]))
+        assert np.max(np.abs(got - ref)) <= 2e-5 * np.max(np.abs(ref)), mode
+        got2 = res[mode][0][1].astype(np.float64) * np.exp(float(res[mode][1][1]))
+        assert np.max(np.abs(got2 - 8 * ref)) <= 2e-5 * np.max(np.abs(8 * ref)), mode
+
+
+@pytest.mark.parametrize("mode", ["zipl", "zip64", "zip128"])
+def test_zipper_forms_on_a_chain_with_uneven_bonds(mode, monkeypatch):
+    """<phi|psi> where psi's bonds are 256, 272, 256, 256, 144 (phi's all 256): a pair is only taken by the fused forms when
+    ITS shape fits (K1 = 256 for the latency form, |u| a multiple of 16 / 64 / 128), so fused and plain launches alternate
+    along the chain: a latency-form pair whose successor is a plain step hands its slabs to k_zip_slab_sum, the next one
+    starts from a plain tensor again, 17 and 9 u-blocks per network leave the XCD remap a remainder.  Against the oracle,
+    two replicas, three runs for bit-identity."""
+    from contractn_amd import TN
+    from oracle import cpu_ref
+    from tests import networks as nets
+
+    n, phys = 7, 4
+    psi_b = [256, 272, 256, 256, 144, 256]
+    rng = np.random.default_rng(41)
+
+    def cores(bonds):
+        out = []
+        for i in range(n):
+            shape = (phys, bonds[0]) if i == 0 else (phys, bonds[-1]) if i == n - 1 else (phys, bonds[i - 1], bonds[i])
+            out.append((rng.standard_normal(shape) / 16.0).astype(np.float32))
+        return out
+
+    tn = TN()
+    a_nodes = nets.add_mps(tn, cores(psi_b))
+    b_nodes = nets.add_mps(tn, cores([256] * (n - 1)))
+    for x, y in zip(a_nodes, b_nodes):
+        tn.connect_nodes(x, y, 0, 0)
+    from contractn_amd.paths import ssa_to_linear
+
+    path = ssa_to_linear(nets.zipper_path(n), 2 * n)
+    shapes = [p.shape for p in tn.params]
+    sets = [list(tn.params), [(p * np.float32(1.5)).astype(np.float32) for p in tn.params]]
+    env = {"zipl": {"CTN_ZIP": "0", "CTN_ZIPL": "1"}, "zip64": {"CTN_ZIP": "2", "CTN_ZIPL": "0"}, "zip128": {"CTN_ZIP": "1", "CTN_ZIPL": "0"}}[mode]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    E.clear_caches()
+    bc = E.BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=2)
+    t, c = bc.run_host(sets)
+    for _ in range(2):
+        t2, c2 = bc.run_host(sets)
+        assert np.array_equal(t, t2) and np.array_equal(c, c2)
+    tiles = bc.executor.step_tiles()
+    bc.executor.close()
+    for k in env:
+        monkeypatch.delenv(k)
+    E.clear_caches()
+    fused = [tl for tl in tiles if tl in ((32, 256), (64, 256), (512, 128), (512, 256))]
+    assert len(fused) >= (3 if mode == "zipl" else 1), tiles
+    for r in range(2):
+        rt, rc = cpu_ref.contract(tn.einsum_str, *sets[r], path=path, split_format=True)
+        assert float(t[r]) == float(rt) and abs(float(c[r]) - float(rc)) <= 1e-4, (mode, r, float(c[r]), float(rc))
 
 
 # ---- a batched MPS as ONE launch (k_sweep_f32): 16 inputs per workgroup walk every site of the chain --------------------
