@@ -71,6 +71,7 @@ struct DevSwitches {
                          // 8: 4.1 / 4.4, 16: 8.5 / 7.0)
   int g_big_min_k = 1024;  // CTN_G_BIG_MIN_K: least K from which full long-K steps of any width take the 256 x 256 tiles
                            // (1536 until round 4; K = 1024, N = 1024: CP r = n = 1024 16.4 -> 15.9 ms, Tucker 15.8 -> 15.7 per mode product)
+  int g_big = 1;         // CTN_G_BIG=0: never the 256 x 256 tiles (experiments)
   int g_splitk = 1;      // CTN_G_SPLITK=0: no K split over workgroups on the large-tile kernel
   int zipl_mp = 0;       // CTN_ZIPL_MP=32|64: force the part of m1 a k_zip_lat workgroup owns (tests)
   bool g_no_asm = false; // CTN_G_NO_ASM: C++ inner loop instead of the hand-scheduled blocks
@@ -93,6 +94,7 @@ static DevSwitches read_dev_switches() {
   d.zipl_max_r = num("CTN_ZIPL_MAX_R", 8);
   d.zipl_mp = num("CTN_ZIPL_MP", 0);
   d.g_splitk = num("CTN_G_SPLITK", 1);
+  d.g_big = num("CTN_G_BIG", 1);
   d.g_big_min_k = num("CTN_G_BIG_MIN_K", 1024);
   d.dot_tr = num("CTN_DOT_TR", 1);
   d.sweep = num("CTN_SWEEP", -1);
@@ -1141,7 +1143,7 @@ static int exec_launch_steps(Exec* E) {
           // 133.9 vs 130.3 TFLOP/s); K = 256 steps (116.0 vs 116.7) and wide outputs (8192 x 8192 x 768: 130.3 vs
           // 132.1) are better off with 256 x 128
           // - and so are very long K on any width (K = 2048 ... 8192: +1.5 ... +3 %)
-          const bool big = use_g == 1 && !kcontig && st.M % 256 == 0 && st.N % 256 == 0 && st.K % GK == 0 &&
+          const bool big = use_g == 1 && E->sw.g_big && !kcontig && st.M % 256 == 0 && st.N % 256 == 0 && st.K % GK == 0 &&
                            ((st.K >= 512 && st.N <= 512) || st.K >= E->sw.g_big_min_k) && gtiles / 2 >= (int64_t)E->n_cu;
           if (big) {
             used_tile(256, 256);

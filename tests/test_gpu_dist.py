@@ -614,3 +614,30 @@ def test_bench_peps_under_a_one_rank_launcher_over_rccl():
     assert line["n_gpus"] == 1 and line["config"]["slices"] >= 64 and line["value"] > 0
     assert line["unsliced_check"]["ok"], line["unsliced_check"]
     assert line["cpu_baseline"]["parity_vs_gpu"]["ok"], line["cpu_baseline"]
+
+
+def test_report_suspect_makes_an_executor_stay_eager_after_three_runs_in_a_row():
+    """`ctn_exec_report_suspect` (round-3 advice): a caller that checks the range itself and never fetches - the staged
+    sliced contraction - tells the executor the verdict once per run; a clean run resets the streak, the third suspect run
+    in a row leaves the executor in the eager rescale mode for good (its runs are then never suspect), and the values stay
+    the oracle's."""
+    from contractn_amd import einsum as E
+    from oracle import cpu_ref
+
+    rng = np.random.default_rng(3)
+    ops = [rng.standard_normal((96, 64)).astype(np.float32), rng.standard_normal((64, 80)).astype(np.float32),
+           rng.standard_normal((80, 8)).astype(np.float32)]
+    bc = E.BatchedContraction("ab,bc,cd->ad", [o.shape for o in ops], np.float32, optimize=((0, 1), (0, 1)), replicas=1)
+    ex = bc.executor
+    t0, c0 = bc.run_host([ops])
+    assert ex.report_suspect(True) == 1 and ex.report_suspect(True) == 2 and ex.report_suspect(False) == 0
+    assert ex.set_rescale_mode(0) == 0                       # still lazy
+    assert [ex.report_suspect(True) for _ in range(3)] == [1, 2, 3]
+    t1, c1 = bc.run_host([ops])                              # an eager run now
+    assert ex.set_rescale_mode(0) == 1                       # ... the executor had switched itself
+    rt, rc = cpu_ref.contract("ab,bc,cd->ad", *ops, path=[(0, 1), (0, 1)], split_format=True)
+    for t, c in ((t0, c0), (t1, c1)):
+        got = t[0].astype(np.float64) * np.exp(float(c[0]))
+        ref = np.asarray(rt, dtype=np.float64) * np.exp(float(rc))
+        assert np.max(np.abs(got - ref)) <= 2e-5 * np.max(np.abs(ref))
+    ex.close()
