@@ -288,6 +288,11 @@ class Plan:
         self._lib = lib
         self.n_inputs = len(in_labels)
         self.n_steps = len(steps)
+        # element offsets of the operands inside one packed host buffer (Executor.run_host packs many small operands)
+        numels = [int(np.prod(shp, dtype=np.int64)) if len(shp) else 1 for shp in in_dims]
+        self.in_numel_total = int(sum(numels))
+        self.in_offsets_bytes = (np.concatenate([[0], np.cumsum(numels[:-1])]) if numels else np.zeros(0)).astype(np.uint64) \
+            * np.uint64(self.np_dtype.itemsize)
         nd = lib.ctn_plan_out_ndim(handle)
         od = (C.c_int64 * max(nd, 1))()
         _check(lib.ctn_plan_out_dims(handle, od))
@@ -365,8 +370,22 @@ class Executor:
     def _run_host_locked(self, operand_sets):
         plan, R = self.plan, self.replicas
         keep = []
-        ptrs = (C.c_void_p * (R * plan.n_inputs))()
-        for r, ops in enumerate(operand_sets):
+        packed = None
+        if R == 1 and plan.n_inputs >= 32 and plan.in_numel_total <= (1 << 20):
+            # many small operands (a 1000-matrix chain, a 100-vector hyperedge): ONE concatenate into a buffer of the plan's
+            # dtype and the pointers by vector arithmetic, instead of a type check and an address look-up per operand
+            # (1001 operands: 1.6 ms of the 3.9 ms call)
+            ops = operand_sets[0]
+            assert len(ops) == plan.n_inputs
+            flat = np.concatenate([np.asarray(o).ravel() for o in ops], dtype=plan.np_dtype, casting="unsafe")
+            if flat.size == plan.in_numel_total:
+                packed = flat
+                addr = (plan.in_offsets_bytes + np.uint64(flat.ctypes.data)).astype(np.uint64)
+                keep.append(addr)
+                ptrs = (C.c_void_p * plan.n_inputs).from_buffer(addr)
+        if packed is None:
+            ptrs = (C.c_void_p * (R * plan.n_inputs))()
+        for r, ops in enumerate(operand_sets if packed is None else ()):
             assert len(ops) == plan.n_inputs
             for i, op in enumerate(ops):
                 if not (isinstance(op, np.ndarray) and op.dtype == plan.np_dtype and op.flags.c_contiguous):
