@@ -511,10 +511,10 @@ def peps_quoted_size():
     """Which PEPS size the strong-scaling claim is quoted on, and the per-rank evidence one GPU allows (round-3 verdict,
     item 1): `tools/peps_rank_time.py` builds and times EVERY rank's share of the staged plan for world = 2, 4, 8 on one
     GPU; the committed summaries (profiles/r04_peps_D{8,16}_rank_time.jsonl) are attached with their source - they are NOT
-    measured in this run.  D = 8 is 0.12 TFLOP per contraction: 2.9 ms on one GPU, and a rank's share at 8 ranks is 0.96 ms
-    of 7-us launches whatever its slice count (predicted 2.9 x); D = 16 (247 TFLOP unsliced, 4096 slices in stages, 6.5 s
+    measured in this run.  D = 8 is 0.12 TFLOP per contraction: 3 ms on one GPU, and a rank's share at 8 ranks is ~0.9 ms
+    of 7-us launches whatever its slice count (predicted 3.2 x); D = 16 (247 TFLOP unsliced, 4096 slices in stages, 6.5 s
     on one GPU) is the size whose work is large enough to shard: quoted."""
-    out = {"size": "D16", "why": ("8 x 8, D = 8 is 0.12 TFLOP: 2.9 ms on ONE GPU, a rank's share at 8 ranks is ~1 ms of "
+    out = {"size": "D16", "why": ("8 x 8, D = 8 is 0.12 TFLOP: 3 ms on ONE GPU, a rank's share at 8 ranks is ~0.9 ms of "
                                   "latency-bound launches; D = 16 (4096 slices, 6.5 s on one GPU) is quoted for strong scaling"),
            "predicted_from_one_gpu_rank_timing": {}}
     for bond in (8, 16):
