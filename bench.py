@@ -1279,6 +1279,9 @@ def kernel_label(key):
     if kind == 2 and tn == 256 and tm in (32, 64):
         return (f"k_zip_lat<Q,{tm}> (two zipper GEMM steps per launch, latency form: 16 values of u x {tm} of m1 "
                 f"per workgroup, partial results as {256 // tm} slabs that the next pair adds up while loading)")
+    if kind == 2 and tm == 256 and tn > 256:
+        return (f"k_mfma_f32_ares<{mb}> (the 256 x 256 left operand resident in registers, {tn // 128} column tiles of 128 per "
+                f"workgroup, only the right operand streams)")
     if kind == 2 and tm == 256:
         return f"k_mfma_f32_g<{'8' if tn == 256 else '4'},2,asm,{ma},{mb}> ({tm}x{tn} tiles, LDS-DMA ring)"
     if kind == 3 and tn == 128:

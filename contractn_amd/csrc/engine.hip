@@ -31,6 +31,7 @@
 #include "kernels_mfma_g.h"
 #include "kernels_mfma_g64.h"
 #include "kernels_mfma_h.h"
+#include "kernels_mfma_ares.h"
 #include "kernels_zip.h"
 #include "kernels_zip64.h"
 #include "kernels_zipl.h"
@@ -71,6 +72,8 @@ struct DevSwitches {
                          // 8: 4.1 / 4.4, 16: 8.5 / 7.0)
   int g_big_min_k = 1024;  // CTN_G_BIG_MIN_K: least K from which full long-K steps of any width take the 256 x 256 tiles
                            // (1536 until round 4; K = 1024, N = 1024: CP r = n = 1024 16.4 -> 15.9 ms, Tucker 15.8 -> 15.7 per mode product)
+  int ares = -1;         // CTN_ARES: 0 never the resident-left-operand kernel (k_mfma_f32_ares), 1 whenever the step's shape allows (tests)
+  int ares_ntw = 0;      // CTN_ARES_NTW: column tiles per workgroup of that kernel (tests)
   int g_big = 1;         // CTN_G_BIG=0: never the 256 x 256 tiles (experiments)
   int g_splitk = 1;      // CTN_G_SPLITK=0: no K split over workgroups on the large-tile kernel
   int zipl_mp = 0;       // CTN_ZIPL_MP=32|64: force the part of m1 a k_zip_lat workgroup owns (tests)
@@ -95,6 +98,8 @@ static DevSwitches read_dev_switches() {
   d.zipl_mp = num("CTN_ZIPL_MP", 0);
   d.g_splitk = num("CTN_G_SPLITK", 1);
   d.g_big = num("CTN_G_BIG", 1);
+  d.ares = num("CTN_ARES", -1);
+  d.ares_ntw = num("CTN_ARES_NTW", 0);
   d.g_big_min_k = num("CTN_G_BIG_MIN_K", 1024);
   d.dot_tr = num("CTN_DOT_TR", 1);
   d.sweep = num("CTN_SWEEP", -1);
@@ -179,6 +184,9 @@ struct Exec {
   double* d_sweep_z = nullptr;         // [R][S]
   double* d_sweep_la = nullptr;        // [R][S][J] logs of d_sweep_a / d_sweep_s
   double* d_sweep_ls = nullptr;
+  // steps with a small resident left operand against a very wide right one (kernels_mfma_ares.h): column tiles per workgroup
+  // (bit 16: the left operand takes 16-byte loads), 0 = not taken
+  std::vector<int> ares_ntw;
   // full dots of a tensor with a transposed one (k_dot_tr), found on the plan's tables when the executor is created
   struct DotTr { bool on = false; int Ka = 0, Kb = 0, x_is_a = 1; int64_t ldY = 0; };
   std::vector<DotTr> dot_tr;
@@ -737,6 +745,54 @@ static bool dot_tr_match(const Plan& P, const Step& st, Exec::DotTr* d) {
   return false;
 }
 
+// Can step s run on k_mfma_f32_ares, and how many 128-column tiles should a workgroup walk?  Checked on the plan's own
+// tables (0 = no): M = K = 256, one batch entry, N a multiple of 128, B vector-loadable along n or along k, every
+// 128-column tile of C dense, more workgroup partials than slots (the step already goes through k_collapse), and
+// enough tiles that workgroups of at least four fill the chip's last round.
+static int ares_match(const Plan& P, int s, int R, int n_cu, const DevSwitches& sw) {
+  const Step& st = P.steps[s];
+  if (sw.ares == 0 || P.dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.Bt != 1 || st.rhs < 0 || st.lhs2 >= 0 || st.epw ||
+      st.M != AR_M || st.K != AR_K || st.N % AR_TN != 0 || !st.collapse)
+    return 0;
+  if (st.modeB != 1 && st.modeB != 2) return 0;
+  const int32_t* T = P.tables.data();
+  const int32_t *onB = T + st.t.onB, *okB = T + st.t.okB, *onC = T + st.t.onC;
+  for (int64_t n = 0; n < st.N; ++n)
+    if (onC[n] != onC[n & ~(int64_t)(AR_TN - 1)] + (n & (AR_TN - 1))) return 0;
+  if (st.modeB == 1) {
+    for (int64_t n = 0; n < st.N; n += 4)
+      if (onB[n + 1] != onB[n] + 1 || onB[n + 2] != onB[n] + 2 || onB[n + 3] != onB[n] + 3 || onB[n] % 4) return 0;
+  } else {
+    for (int k = 0; k < AR_K; k += 4)
+      if (okB[k + 1] != okB[k] + 1 || okB[k + 2] != okB[k] + 2 || okB[k + 3] != okB[k] + 3 || okB[k] % 4) return 0;
+    for (int64_t n = 0; n < st.N; ++n) if (onB[n] % 4) return 0;
+  }
+  const int64_t tiles = st.N / AR_TN;
+  if (sw.ares != 1 && tiles * 2 * R < 2LL * n_cu) return 0;         // (the throughput regime of the large-tile kernel)
+  if (sw.ares_ntw > 0) return tiles % sw.ares_ntw == 0 ? sw.ares_ntw : 0;
+  // as many tiles per workgroup as still fill the last round of workgroups (a workgroup's load of A costs about a
+  // quarter of a tile), at least 4
+  for (int ntw : {64, 32, 16, 8, 4}) {
+    if (tiles % ntw) continue;
+    const int64_t wgs = tiles / ntw * R, rounds = (wgs + n_cu - 1) / n_cu;
+    if (wgs * 100 >= rounds * n_cu * 94) return ntw;
+  }
+  return sw.ares == 1 && tiles % 4 == 0 ? 4 : 0;
+}
+
+// ... and can the resident operand be fetched with 16-byte loads along k?
+static bool ares_avec(const Plan& P, int s) {
+  const Step& st = P.steps[s];
+  if (st.modeA != 2) return false;
+  const int32_t* T = P.tables.data();
+  const int32_t *omA = T + st.t.omA, *okA = T + st.t.okA, *obA = T + st.t.obA;
+  if (obA[0] % 4 || P.tensors[st.lhs].numel % 4) return false;
+  for (int k = 0; k < AR_K; ++k) if (okA[k] != okA[0] + k) return false;
+  if (okA[0] % 4) return false;
+  for (int m = 0; m < AR_M; ++m) if (omA[m] % 4) return false;
+  return true;
+}
+
 static int exec_launch_steps(Exec* E) {
   const Plan& P = *E->plan;
   const int R = E->R;
@@ -1025,6 +1081,24 @@ static int exec_launch_steps(Exec* E) {
       case CTN_KERNEL_MFMA_F32: {
         const int64_t total = (int64_t)st.blocks * R;
         if (total >= (1LL << 31)) { g_err = "grid too large"; return CTN_UNSUPPORTED; }
+        if (const int ntw_av = (int)E->ares_ntw.size() == P.n_steps ? E->ares_ntw[s] : 0) {
+          const int ntw = ntw_av & 0xffff, avec = ntw_av >> 16;
+          // the left operand resident in registers, `ntw` column tiles per workgroup (k_mfma_f32_ares); one partial per
+          // workgroup through the collapse pass the step has anyway
+          const int wgs = (int)(st.N / AR_TN / ntw);
+          a.partC = E->d_scratch; a.partC_stride = wgs;
+          do_collapse = true; collapse_blocks = wgs;
+          used_tile(256, std::min(AR_TN * ntw, 32768));
+          const dim3 ga((unsigned)((int64_t)wgs * R));
+          if (st.modeB == 2) {
+            if (avec) hipLaunchKernelGGL((k_mfma_f32_ares<2, 1>), ga, dim3(512), 0, E->stream, a, ntw);
+            else hipLaunchKernelGGL((k_mfma_f32_ares<2, 0>), ga, dim3(512), 0, E->stream, a, ntw);
+          } else {
+            if (avec) hipLaunchKernelGGL((k_mfma_f32_ares<1, 1>), ga, dim3(512), 0, E->stream, a, ntw);
+            else hipLaunchKernelGGL((k_mfma_f32_ares<1, 0>), ga, dim3(512), 0, E->stream, a, ntw);
+          }
+          break;
+        }
         if (const int S = (E->d_slab && s + 1 < P.n_steps) ? g_splitk(st, R, E->n_cu, E->mfma_g, E->sw, st.cvec) : 0) {
           SplitKArgs sk{};
           sk.slab = E->d_slab;
@@ -1744,6 +1818,16 @@ int ctn_exec_create(const ctn_plan* plan, int device, void* stream, int replicas
     bool any = false;
     for (int s = 0; s < P.n_steps; ++s) any = dot_tr_match(P, P.steps[s], &E.dot_tr[s]) || any;
     if (!any) E.dot_tr.clear();
+  }
+  // steps with a resident left operand (k_mfma_f32_ares)
+  if (!P.chain && E.sw.ares != 0 && P.dtype == CTN_F32) {
+    E.ares_ntw.assign(P.n_steps, 0);
+    bool any = false;
+    for (int s = 0; s < P.n_steps; ++s) { E.ares_ntw[s] = ares_match(P, s, replicas, E.n_cu, E.sw);
+      if (E.ares_ntw[s] && ares_avec(P, s)) E.ares_ntw[s] |= 1 << 16;
+      any = any || E.ares_ntw[s];
+    }
+    if (!any) E.ares_ntw.clear();
   }
   // a sweep: at least half a chip of row blocks, or CTN_SWEEP=1
   if (!P.chain && E.sw.sweep != 0 && P.stabilize) {

@@ -1288,6 +1288,68 @@ def test_large_tile_kernel_with_k_split_over_workgroups(einstr, shapes, monkeypa
         assert np.max(np.abs(got2 - 8 * ref)) <= 2e-5 * np.max(np.abs(8 * ref)), mode
 
 
+@pytest.mark.parametrize("einstr,shapes", [
+    # (the operand popped from the higher position is the step's left one, reference einsum.py:344: the small matrix second)
+    ("kn,km,n->m", [(256, 65536), (256, 256), (65536,)]),          # B row-contiguous along n: k_mfma_f32_ares<1>
+    ("nk,mk,n->m", [(65536, 256), (256, 256), (65536,)]),          # B k-contiguous: <2>; A row-major
+    ("kxy,km,xy->m", [(256, 2048, 48), (256, 256), (2048, 48)]),   # columns = two legs, the inner one 48 long: a tile's
+])                                                                  # 16-byte pieces are gathered through the table
+def test_resident_left_operand_kernel(einstr, shapes, monkeypatch):
+    """A 256 x 256 left operand against a very wide right one (the boundary absorptions of a 2D grid at bond 16): A lives
+    in registers, a workgroup walks several 128-column tiles, only B streams (k_mfma_f32_ares).  Against NumPy and against
+    the large-tile kernel (CTN_ARES=0), two replicas, twice for bit-identity."""
+    rng = np.random.default_rng(29)
+    ops = [(rng.standard_normal(s_) / 16.0).astype(np.float32) for s_ in shapes]
+    ref = np.einsum(einstr, *[o.astype(np.float64) for o in ops], optimize=["einsum_path", (0, 1), (0, 1)])
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CTN_ARES", mode)
+        E.clear_caches()
+        bc = E.BatchedContraction(einstr, shapes, np.float32, optimize=((0, 1), (0, 1)), replicas=2)
+        t, c = bc.run_host([ops, [3 * o for o in ops]])
+        t2, c2 = bc.run_host([ops, [3 * o for o in ops]])
+        assert np.array_equal(t, t2) and np.array_equal(c, c2)
+        res[mode] = (t, c, bc.executor.step_tiles())
+        bc.executor.close()
+    monkeypatch.delenv("CTN_ARES")
+    E.clear_caches()
+    assert res["1"][2][0][0] == 256 and res["1"][2][0][1] >= 512, res["1"][2]        # (256, 128 x tiles per workgroup)
+    assert res["0"][2][0] in ((256, 128), (256, 256)), res["0"][2]
+    for mode in ("1", "0"):
+        got = res[mode][0][0].astype(np.float64) * np.exp(float(res[mode][1][0]))
+        assert np.max(np.abs(got - ref)) <= 2e-5 * np.max(np.abs(ref)), mode
+        got2 = res[mode][0][1].astype(np.float64) * np.exp(float(res[mode][1][1]))
+        assert np.max(np.abs(got2 - 27 * ref)) <= 2e-5 * np.max(np.abs(27 * ref)), mode
+
+
+def test_resident_left_operand_kernel_as_the_last_step(monkeypatch):
+    """The same kernel on the step that writes the caller's result (no consumer behind it: k_finalize takes its collapsed
+    partials), the result kept in caller order `mn`; CTN_ARES_NTW pins the tiles per workgroup."""
+    rng = np.random.default_rng(31)
+    einstr, shapes = "kn,km->mn", [(256, 131072), (256, 256)]
+    ops = [(rng.standard_normal(s_) * 7.0).astype(np.float32) for s_ in shapes]
+    ref = ops[1].astype(np.float64).T @ ops[0].astype(np.float64)
+    res = {}
+    for mode, ntw in (("1", "0"), ("1", "8"), ("0", "0")):
+        monkeypatch.setenv("CTN_ARES", mode)
+        monkeypatch.setenv("CTN_ARES_NTW", ntw)
+        E.clear_caches()
+        bc = E.BatchedContraction(einstr, shapes, np.float32, optimize=((0, 1),), replicas=1)
+        t, c = bc.run_host([ops])
+        res[mode + ntw] = (t, c, bc.executor.step_tiles())
+        bc.executor.close()
+    monkeypatch.delenv("CTN_ARES")
+    monkeypatch.delenv("CTN_ARES_NTW")
+    E.clear_caches()
+    assert res["10"][2][0][0] == 256 and res["10"][2][0][1] >= 512, res["10"][2]
+    assert res["18"][2][0] == (256, 1024), res["18"][2]
+    assert res["00"][2][0] in ((256, 128), (256, 256)), res["00"][2]
+    for key in res:
+        got = res[key][0][0].astype(np.float64) * np.exp(float(res[key][1][0]))
+        assert np.max(np.abs(got - ref)) <= 2e-5 * np.max(np.abs(ref)), key
+    assert np.array_equal(res["10"][1], res["18"][1]) or abs(float(res["10"][1][0]) - float(res["18"][1][0])) < 1e-5
+
+
 @pytest.mark.parametrize("mode", ["zipl", "zip64", "zip128"])
 def test_zipper_forms_on_a_chain_with_uneven_bonds(mode, monkeypatch):
     """<phi|psi> where psi's bonds are 256, 272, 256, 256, 144 (phi's all 256): a pair is only taken by the fused forms when
