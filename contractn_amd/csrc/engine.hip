@@ -746,12 +746,12 @@ static bool dot_tr_match(const Plan& P, const Step& st, Exec::DotTr* d) {
 }
 
 // Can step s run on k_mfma_f32_ares, and how many 128-column tiles should a workgroup walk?  Checked on the plan's own
-// tables (0 = no): M = K = 256, one batch entry, N a multiple of 128, B vector-loadable along n or along k, every
+// tables (0 = no): M = K = 256, N a multiple of 128, B vector-loadable along n or along k, every
 // 128-column tile of C dense, more workgroup partials than slots (the step already goes through k_collapse), and
 // enough tiles that workgroups of at least four fill the chip's last round.
 static int ares_match(const Plan& P, int s, int R, int n_cu, const DevSwitches& sw) {
   const Step& st = P.steps[s];
-  if (sw.ares == 0 || P.dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.Bt != 1 || st.rhs < 0 || st.lhs2 >= 0 || st.epw ||
+  if (sw.ares == 0 || P.dtype != CTN_F32 || st.kernel != CTN_KERNEL_MFMA_F32 || st.rhs < 0 || st.lhs2 >= 0 || st.epw ||
       st.M != AR_M || st.K != AR_K || st.N % AR_TN != 0 || !st.collapse)
     return 0;
   if (st.modeB != 1 && st.modeB != 2) return 0;
@@ -767,7 +767,8 @@ static int ares_match(const Plan& P, int s, int R, int n_cu, const DevSwitches& 
       if (okB[k + 1] != okB[k] + 1 || okB[k + 2] != okB[k] + 2 || okB[k + 3] != okB[k] + 3 || okB[k] % 4) return 0;
     for (int64_t n = 0; n < st.N; ++n) if (onB[n] % 4) return 0;
   }
-  const int64_t tiles = st.N / AR_TN;
+  const int64_t tiles = st.N / AR_TN;       // per batch entry: a workgroup's tiles are tiles of one matrix
+  R *= (int)st.Bt;
   if (sw.ares != 1 && tiles * 2 * R < 2LL * n_cu) return 0;         // (the throughput regime of the large-tile kernel)
   if (sw.ares_ntw > 0) return tiles % sw.ares_ntw == 0 ? sw.ares_ntw : 0;
   // as many tiles per workgroup as still fill the last round of workgroups (a workgroup's load of A costs about a
@@ -1085,7 +1086,7 @@ static int exec_launch_steps(Exec* E) {
           const int ntw = ntw_av & 0xffff, avec = ntw_av >> 16;
           // the left operand resident in registers, `ntw` column tiles per workgroup (k_mfma_f32_ares); one partial per
           // workgroup through the collapse pass the step has anyway
-          const int wgs = (int)(st.N / AR_TN / ntw);
+          const int wgs = (int)(st.Bt * (st.N / AR_TN / ntw));
           a.partC = E->d_scratch; a.partC_stride = wgs;
           do_collapse = true; collapse_blocks = wgs;
           used_tile(256, std::min(AR_TN * ntw, 32768));

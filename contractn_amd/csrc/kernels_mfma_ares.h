@@ -37,7 +37,7 @@ namespace ctn {
 // a tile's first k-tile waits with vmcnt(63) - the k-tile it needs was requested BEFORE the previous tile's 64 stores
 // per lane, of which all but the first stay in flight.
 //
-// Conditions (engine.hip, ares_match): fp32, one batch entry, M = K = 256, N a multiple of 128, B in mode 1 or 2, C
+// Conditions (engine.hip, ares_match): fp32, M = K = 256 (any number of batch entries), N a multiple of 128, B in mode 1 or 2, C
 // with every 128-column tile dense, more workgroup partials than slots (the collapse path: N >= 32768).
 // ---------------------------------------------------------------------------
 constexpr int AR_M = 256, AR_K = 256, AR_TN = 128, AR_KT = 32, AR_ST = 3;
@@ -91,15 +91,18 @@ __global__ __launch_bounds__(512, 1) void k_mfma_f32_ares(StepArgs a, int ntw) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
   const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  const int per = (a.N / AR_TN) / ntw;          // workgroups per replica
-  const int r = pid / per;
-  const int t_ = pid - r * per;
+  const int per = (a.N / AR_TN) / ntw;          // workgroups per batch entry
+  const int perR = per * a.Bt;                  // ... per replica
+  const int r = pid / perR;
+  const int rem = pid - r * perR;               // (the workgroup's partial-sum slot)
+  const int bt = rem / per;
+  const int t_ = rem - bt * per;
   const int n_first = t_ * ntw * AR_TN;         // first column of this workgroup
 
   void* const* tp = a.ptrs + (size_t)r * a.n_tensors;
-  const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[0];
-  const char* const Bc = reinterpret_cast<const char*>((const float*)tp[a.idB] + a.obB[0]);
-  float* __restrict__ C = (float*)tp[a.idC] + a.obC[0];
+  const float* __restrict__ A = (const float*)tp[a.idA] + a.obA[bt];
+  const char* const Bc = reinterpret_cast<const char*>((const float*)tp[a.idB] + a.obB[bt]);
+  float* __restrict__ C = (float*)tp[a.idC] + a.obC[bt];
 
   for (int k = tid; k < AR_K; k += 512) { s_okA[k] = a.okA[k]; s_okB[k] = a.okB[k]; s_omC[k] = a.omC[k]; }
   double pva = 0.0, pvb = 0.0;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(512, 1) void k_mfma_f32_ares(StepArgs a, int ntw) {
     double tot = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) tot += red[i];
-    a.partC[(size_t)r * a.partC_stride + t_] = tot;
+    a.partC[(size_t)r * a.partC_stride + rem] = tot;
   }
 }
 

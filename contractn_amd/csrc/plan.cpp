@@ -444,6 +444,20 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
         bool anyM = false, anyN = false;
         for (auto& l : info) if (l.inC) { if (l.inA && !l.inB) anyM = true; if (l.inB && !l.inA) anyN = true; }
         if (anyM && !anyN) swap = true;
+        // A very wide operand against a small one over K = 256 (a boundary tensor of a 2D grid absorbing a site: 2^20 x 256
+        // x 256): the small one goes LEFT - the engine then keeps it in registers while the wide one streams
+        // (k_mfma_f32_ares), and reads it through its tables whatever its layout, where a right operand that is
+        // unit-stride along neither n nor k sends the whole step to the 4-byte-gather kernel.
+        bool small_left = false, keep_sides = false;
+        if (P.dtype == CTN_F32 && anyM && anyN) {
+          int64_t eM = 1, eN = 1, eK = 1;
+          for (auto& l : info) {
+            if (!l.inC) eK *= l.ext;
+            else if (l.inA && !l.inB) eM *= l.ext;
+            else if (l.inB && !l.inA) eN *= l.ext;
+          }
+          small_left = eK == 256 && eN == 256 && eM >= 32768;
+        }
         // A result of 2^31 elements or more is laid out [batch][M][N]; the step that consumes it can address a
         // CONTRACTED group only through a 32-bit table, so the labels it sums must be the inner (column) ones: when
         // they all come from the left operand, the operands change sides.
@@ -462,8 +476,10 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
             bool sumM = false, sumN = false;
             for (auto& l : info) if (l.inC && !kept(l.label)) { if (l.inA && !l.inB) sumM = true; if (l.inB && !l.inA) sumN = true; }
             if (sumM && !sumN) swap = true;
+            if (sumN && !sumM) keep_sides = true;
           }
         }
+        if (small_left && !keep_sides) swap = true;
       }
     }
     if (swap) {
@@ -506,6 +522,39 @@ int build_plan(const ctn_plan_desc& d, Plan& P, std::string& err) {
     bool kOrderA = !(bUnitInK && !aUnitInK);
     if (aUnitInK && bUnitInK && rhs >= 0 && P.tensors[rhs].numel > P.tensors[lhs].numel) kOrderA = false;
     std::stable_sort(G[kK].begin(), G[kK].end(), by(kOrderA));
+
+    // A result of 2^31 elements or more (an 8 x 8 grid at bond 16 sliced over two labels only: 2^32-element boundary
+    // tensors): the row / column tables hold 32-bit offsets, so free labels have to become batch labels (64-bit offsets)
+    // until one batch entry's matrix is below 2^31 elements.  Which ones is decided HERE, before the layout: the outer
+    // labels of the LARGER free group go, and as batch labels they are the outermost of the result - the small group
+    // stays whole (256 rows against 2^24 columns keep their 256 rows: large tiles, the resident-operand kernel; taken
+    // from the result's own outermost label afterwards, as the span rule below would, they became 16 rows).
+    if (!last && !fused && !epw && rhs >= 0 && !G[kK].empty()) {   // (element-wise products: their own rule below)
+      auto ext_of = [](const std::vector<LabelInfo*>& g) { double n = 1.0; for (auto* l : g) n *= (double)l->ext; return n; };
+      double out_n = 1.0;
+      for (auto& l : info) if (l.inC) out_n *= (double)l.ext;
+      if (out_n >= 2147483648.0) {
+        // ... and of those, labels the consuming step KEEPS: what it sums has to stay inside one batch entry's matrix
+        // (a contracted group is addressed through a 32-bit table)
+        int s2 = -1;
+        for (int q = s + 1; q < d.n_steps && s2 < 0; ++q) if (d.step_lhs[q] == out_id || d.step_rhs[q] == out_id) s2 = q;
+        int64_t o2 = 0;
+        for (int q = 0; q < s2; ++q) o2 += d.step_out_ndim[q];
+        auto kept = [&](int32_t lab) {
+          if (s2 < 0) return true;
+          for (int a_ = 0; a_ < d.step_out_ndim[s2]; ++a_) if (d.step_out_labels[o2 + a_] == lab) return true;
+          return false;
+        };
+        while (ext_of(G[kM]) * ext_of(G[kN]) >= 2147483648.0) {
+          const int cls = ext_of(G[kN]) >= ext_of(G[kM]) ? kN : kM;
+          if (G[cls].size() <= 1) break;
+          auto it = std::find_if(G[cls].begin(), G[cls].end(), [&](LabelInfo* l) { return kept(l->label); });
+          if (it == G[cls].end()) it = G[cls].begin();
+          G[kBatch].push_back(*it);
+          G[cls].erase(it);
+        }
+      }
+    }
 
     // -- output tensor and its layout
     Tensor out;

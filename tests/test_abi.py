@@ -162,3 +162,33 @@ def test_planner_selects_large_tile_kernels():
     # fewer than two k-tiles
     assert info("km,kn->mn", [(16, 256), (16, 256)], "float32")["tile_m"] == 128
     assert info("km,kn->mn", [(8, 128), (8, 128)], "float64")["tile_n"] == 64
+
+
+def test_planner_puts_a_small_operand_left_of_a_very_wide_one():
+    """K = 256, 256 free values on one side and >= 32768 on the other (a 2D grid's boundary absorbing a site): the small
+    operand becomes the step's left one whatever the caller's order - the engine keeps it in registers (k_mfma_f32_ares)."""
+    from contractn_amd import einsum as E
+
+    def first(einstr, shapes):
+        clist = E._contract_path(einstr, tuple(shapes), optimize=((0, 1), (0, 1)), memory_limit=None, use_blas=True)
+        return E._native_plan(clist, tuple(shapes), "float32").step_infos()[0]
+
+    a = first("km,kn,n->m", [(256, 256), (256, 65536), (65536,)])      # the wide operand popped second: it would be the left one
+    b = first("kn,km,n->m", [(256, 65536), (256, 256), (65536,)])
+    for i in (a, b):
+        assert (i["m"], i["n"], i["k"], i["tile_m"]) == (256, 65536, 256, 256), i
+    assert a["swapped"] == 1 and b["swapped"] == 0
+    c = first("km,kn,n->m", [(256, 128), (256, 65536), (65536,)])      # 128 free values: not this rule
+    assert c["m"] == 65536 and c["swapped"] == 0
+
+
+def test_results_of_2_to_32_elements_keep_their_small_group_whole():
+    """256 rows against 2^24 columns (three legs of 256): the outermost column leg becomes a batch label, outermost in the
+    result, and every batch entry is a 256 x 65536 matrix - not 2^24 columns against ONE row per batch entry."""
+    from contractn_amd import einsum as E
+
+    shapes = [(256, 256), (256, 256, 256, 256), (256,)]
+    clist = E._contract_path("km,xkyz,z->mxy", tuple(shapes), optimize=((0, 1), (0, 1)), memory_limit=None, use_blas=True)
+    i = E._native_plan(clist, tuple(shapes), "float32").step_infos()[0]
+    assert (i["batch"], i["m"], i["n"], i["k"]) == (256, 256, 65536, 256), i
+    assert i["tile_m"] == 256 and i["out_numel"] == 2 ** 32

@@ -1293,7 +1293,9 @@ def test_large_tile_kernel_with_k_split_over_workgroups(einstr, shapes, monkeypa
     ("kn,km,n->m", [(256, 65536), (256, 256), (65536,)]),          # B row-contiguous along n: k_mfma_f32_ares<1>
     ("nk,mk,n->m", [(65536, 256), (256, 256), (65536,)]),          # B k-contiguous: <2>; A row-major
     ("kxy,km,xy->m", [(256, 2048, 48), (256, 256), (2048, 48)]),   # columns = two legs, the inner one 48 long: a tile's
-])                                                                  # 16-byte pieces are gathered through the table
+                                                                    # 16-byte pieces are gathered through the table
+    ("bkn,bkm,bn->bm", [(4, 256, 32768), (4, 256, 256), (4, 32768)]),   # four batch entries, each with its own A
+])
 def test_resident_left_operand_kernel(einstr, shapes, monkeypatch):
     """A 256 x 256 left operand against a very wide right one (the boundary absorptions of a 2D grid at bond 16): A lives
     in registers, a workgroup walks several 128-column tiles, only B streams (k_mfma_f32_ares).  Against NumPy and against

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Regenerate the sliced plans that ship in contractn_amd/plans/ (host only, minutes): the staged plans of the two
-8 x 8 PEPS benchmarks (D = 8 with >= 64 slices; D = 16 under a 2^28-element cap) and of the 5 x 6, D = 16 test
+8 x 8 PEPS benchmarks (D = 8 with >= 64 slices; D = 16 under a 2^28- and a 2^32-element cap) and of the 5 x 6, D = 16 test
 network, each the best of many seeds searched in parallel processes, stored under the cache key of the DEFAULT call
 (`dist.staged_plan(einstr, shapes, min_slices=..., max_intermediate=...)`), so that a GPU box never searches.
 
@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 JOBS = [  # (rows, cols, bond, min_slices, max_intermediate)
     (8, 8, 8, 64, None),
     (8, 8, 16, 64, 2 ** 28),
+    (8, 8, 16, 64, 2 ** 32),
     (5, 6, 16, 16, None),
 ]
 

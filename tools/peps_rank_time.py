@@ -32,7 +32,7 @@ bond = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 worlds = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
 big = bond >= 16
 einstr, shapes, ops = bench.peps_network(8, 8, bond)
-labels, path, rep = cdist.staged_plan(einstr, shapes, min_slices=64, max_intermediate=2 ** 28 if big else None)
+labels, path, rep = cdist.staged_plan(einstr, shapes, min_slices=64, max_intermediate=2 ** 32 if big else None)
 dev = torch.device("cuda", 0)
 warm, iters = (1, 1) if big else (4, 20)
 
