@@ -363,3 +363,47 @@ def test_materialised_tensors_beyond_2_to_the_31_elements():
     del t2
     torch.cuda.empty_cache()
     E.clear_caches()
+
+
+def test_absorption_chain_on_boundary_tensors_of_2_to_the_32_elements():
+    """The steps of the bond-16 grid's 256-slice plan: a 2^32-element boundary tensor (16 GiB) absorbs a 256 x 256 site
+    matrix twice - each result again 2^32 elements - and is then closed over its outer legs.  The planner makes the outermost
+    column leg the consumer keeps a batch label BEFORE laying the result out, so every batch entry is 256 x 2^16..2^20 and the
+    steps run on k_mfma_f32_ares; against the same chain in float64 slab by slab (torch), and the planner's choice
+    is asserted on the executor's launched tiles."""
+    import torch
+
+    from contractn_amd.einsum import BatchedContraction
+
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(33)
+    n = 256
+    Bt = torch.randn((n, n, n, n), generator=gen, device="cuda") * 0.0625           # [x][k][y][z]
+    A1 = torch.randn((n, n), generator=gen, device="cuda") * 0.0625                  # [k][m]
+    A2 = torch.randn((n, n), generator=gen, device="cuda") * 0.0625                  # [y][p]
+    wz = torch.randn((n,), generator=gen, device="cuda")
+    wx = torch.randn((n,), generator=gen, device="cuda")
+    einstr = "km,xkyz,yp,z,x->mp"
+    path = ((0, 1), (0, 3), (0, 2), (0, 1))           # (km . xkyz) -> . yp -> . z -> . x
+    shapes = [tuple(t.shape) for t in (A1, Bt, A2, wz, wx)]
+    bc = BatchedContraction(einstr, shapes, np.float32, optimize=path, replicas=1)
+    infos = bc.plan.step_infos()
+    assert infos[0]["out_numel"] == 2 ** 32 and (infos[0]["m"], infos[0]["k"]) == (256, 256) and infos[0]["batch"] >= 16, infos[0]
+    assert infos[1]["out_numel"] == 2 ** 32 and (infos[1]["m"], infos[1]["k"]) == (256, 256), infos[1]
+    out = torch.zeros((n, n), device="cuda")
+    launch = bc.executor.make_enqueue([t.data_ptr() for t in (A1, Bt, A2, wz, wx)], [out.data_ptr()])
+    launch()
+    logs = bc.fetch_log_scale()
+    tiles = bc.executor.step_tiles()
+    assert tiles[0][0] == 256 and tiles[0][1] >= 512 and tiles[1][0] == 256 and tiles[1][1] >= 512, tiles[:2]
+    got = out.double() * float(np.exp(logs[0]))
+    # float64 reference, one x at a time: R[m, p] = sum_x wx[x] sum_{k, y, z} A1[k, m] B[x, k, y, z] A2[y, p] wz[z]
+    ref = torch.zeros((n, n), device="cuda", dtype=torch.float64)
+    for x in range(n):
+        v = Bt[x].double() @ wz.double()                                             # [k][y]
+        ref += wx[x].double() * (A1.double().T @ v @ A2.double())
+    assert float((got - ref).abs().max() / ref.abs().max()) <= 2e-4
+    bc.executor.close()
+    del Bt, out
+    torch.cuda.empty_cache()
+    E.clear_caches()
