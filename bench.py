@@ -513,10 +513,10 @@ def peps_quoted_size():
     item 1): `tools/peps_rank_time.py` builds and times EVERY rank's share of the staged plan for world = 2, 4, 8 on one
     GPU; the committed summaries (profiles/r04_peps_D{8,16}_rank_time.jsonl) are attached with their source - they are NOT
     measured in this run.  D = 8 is 0.12 TFLOP per contraction: 3 ms on one GPU, and a rank's share at 8 ranks is ~0.9 ms
-    of 7-us launches whatever its slice count (predicted 3.2 x); D = 16 (247 TFLOP unsliced, 4096 slices in stages, 6.5 s
+    of 7-us launches whatever its slice count (predicted 3.2 x); D = 16 (247 TFLOP unsliced, 256 slices over two labels in stages, 4.0 s
     on one GPU) is the size whose work is large enough to shard: quoted."""
     out = {"size": "D16", "why": ("8 x 8, D = 8 is 0.12 TFLOP: 3 ms on ONE GPU, a rank's share at 8 ranks is ~0.9 ms of "
-                                  "latency-bound launches; D = 16 (4096 slices, 6.5 s on one GPU) is quoted for strong scaling"),
+                                  "latency-bound launches; D = 16 (256 slices over two labels, 4.0 s on one GPU) is quoted for strong scaling"),
            "predicted_from_one_gpu_rank_timing": {}}
     for bond in (8, 16):
         f = os.path.join(ROOT, "profiles", f"r04_peps_D{bond}_rank_time.jsonl")
@@ -812,6 +812,7 @@ def run_peps(args, world, rank, local_rank, backend, dev):
     sc = make(einstr, ops, labels, optimize=path, rank=rank, world=world, device=local_rank,
               workspace_budget=int(args.workspace_gib * 2 ** 30))
     stages = sc.stage_list()          # [(BatchedContraction, evaluations on this rank, replicas per launch, launches)]
+    hbm_free, hbm_total = torch.cuda.mem_get_info(dev)       # with every stage buffer and workspace of this rank allocated
     execs = [st[0].executor for st in stages]
     max_chunks = max([st[3] for st in stages], default=1)
 
@@ -843,7 +844,8 @@ def run_peps(args, world, rank, local_rank, backend, dev):
     sync_all()
     elapsed = time.perf_counter() - t0
     under_load = sampler.stop() if sampler else {}
-    stage_ms = [x.step_ms().astype(np.float64) for x in execs]     # per step: mean over the recorded launches
+    # per step: mean over the recorded launches (--event-passes 0, counter-collection runs: none recorded)
+    stage_ms = [x.step_ms().astype(np.float64) if timed_passes else np.zeros(st[0].plan.n_steps) for x, st in zip(execs, stages)]
     for x in execs:
         x.set_timing(0)
     # evaluations per stage over all ranks (a stage below no sliced label is evaluated by every rank: counted each time)
@@ -965,6 +967,7 @@ def run_peps(args, world, rank, local_rank, backend, dev):
             "slices_per_gpu": n_mine,
             "sliced_labels": len(labels),
             "slices_in_flight_per_launch": sc_R,
+            "hbm_free_gib_with_all_stage_buffers_allocated": round(hbm_free / 2 ** 30, 1),
             "outer_labels_walked_on_the_host": sc_outer,
             "labels_the_root_stage_sums_itself": sc_unsliced,
             "execution": ("staged: a stage of the tree is evaluated once per joint value of the sliced labels below it "
@@ -1179,6 +1182,8 @@ def pmc_traffic(workload, kernel):
     except (OSError, ValueError):
         return None, None
     if d.get("workload") != workload or d.get("kernel_label") != kernel or d.get("hbm_bytes_per_launch") is None:
+        return None, None
+    if kernel.split(" ")[0].split("<")[0] not in str(d.get("kernel", "")):     # the counters of another kernel of that run
         return None, None
     return d["hbm_bytes_per_launch"], f"profiles/pmc_traffic.json@{d.get('git_sha', 'unknown')} ({d.get('round', '?')}: {d.get('note', '')})"
 

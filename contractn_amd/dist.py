@@ -1592,6 +1592,14 @@ class StagedSlicedContraction:
                                    not root, st_strides)
             per = max(1, probe.workspace_bytes(2) - probe.workspace_bytes(1))
             R = int(max(1, min(max(len(x) for x in need[k]), workspace_budget // per)))
+            # ... and no more evaluations in flight than the card has room for RIGHT NOW (the budget is per stage; the
+            # stages below, their result buffers and whatever else the process holds are already allocated), 8 GiB spared
+            try:
+                free_b = torch.cuda.mem_get_info(dev)[0]
+                own = stage_stride[k] * item
+                R = int(max(1, min(R, (free_b - (8 << 30) - n_buf * own) // (per + own))))
+            except (RuntimeError, AssertionError, TypeError):
+                pass
             bc = E.BatchedContraction(st_einsum, st_shapes, self.np_dtype, optimize=st["path"], replicas=R, device=device,
                                       stream=self.stage_streams[k].cuda_stream, free_output_order=not root, in_strides=st_strides)
             self.stages.append({
