@@ -1615,3 +1615,38 @@ def test_full_dot_against_a_transposed_tensor(einstr, shapes, dtype, monkeypatch
     assert np.max(np.abs(res["0"] - res["1"])) <= tol * max(1.0, np.max(np.abs(ref)) * 10)
     monkeypatch.delenv("CTN_DOT_TR")
     E.clear_caches()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_wide_absorptions_in_random_layouts(seed):
+    """A boundary tensor absorbing a site in every arrangement a 2D grid produces: the wide operand's legs in random order
+    (the contracted ones anywhere among them), the site tensor's four legs in random order, either operand first.  K = 256
+    and 256 free values on the small side, so the planner puts the small operand left and the step runs on
+    k_mfma_f32_ares when the wide operand is unit-stride along a free or a contracted leg, on the general kernels when
+    it is not; then one more absorption on the result (its layout is the engine's).  Against torch.einsum in float64."""
+    import torch
+
+    rng = np.random.default_rng(1000 + seed)
+    legs = "abcdefg"                                   # wide tensor: 4 free legs (16, 16, 16, 8..32) + 2 contracted (16, 16)
+    free_ext = [16, 16, 16, int(rng.choice([8, 16, 32]))]
+    wide_legs = list("abcd") + list("kl")
+    ext = dict(zip("abcd", free_ext), k=16, l=16, m=16, n=16, p=16, q=16)
+    order = rng.permutation(len(wide_legs))
+    wide = "".join(wide_legs[i] for i in order)
+    site1 = "".join(rng.permutation(list("klmn")))      # contracts k, l; new legs m, n
+    # second absorption: contracts one old free leg and one new leg of the first result
+    site2 = "".join(rng.permutation(list("anpq")))
+    out = "".join(rng.permutation(list("bcdmpq")))
+    terms = [wide, site1, site2]
+    if rng.integers(2):
+        terms = [site1, wide, site2]
+    einstr = ",".join(terms) + "->" + out
+    shapes = [tuple(ext[c] for c in t) for t in terms]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    ops = [torch.randn(s, generator=gen, device="cuda") * 0.25 for s in shapes]
+    t, c = contract(einstr, *ops, optimize=((0, 1), (0, 1)), split_format=True)
+    ref = torch.einsum(einstr, *[o.double() for o in ops])
+    got = t.double() * torch.exp(c.double())
+    assert float((got - ref).abs().max() / ref.abs().max()) <= 2e-5, einstr
+    E.clear_caches()

@@ -11,7 +11,7 @@ where `join_us` is what ONE all_gather of 16 bytes over 8 ranks is ASSUMED to co
 xGMI; 50 us, on the safe side - it cannot be measured on a one-GPU box) and `best_single_gpu_ms` the faster of the
 staged plan with all slices on one GPU and - where it fits - the unsliced network on the library's own path.
 
-    python tools/peps_rank_time.py [bond] [worlds, e.g. 1,2,4,8]  >  profiles/r04_peps_D<bond>_rank_time.jsonl
+    python tools/peps_rank_time.py [bond] [worlds, e.g. 1,2,4,8] [log2 of the bond-16 plan's cap: 32 | 28]  >  profiles/r04_peps_D<bond>_rank_time.jsonl
 """
 import json
 import os
@@ -32,7 +32,8 @@ bond = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 worlds = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
 big = bond >= 16
 einstr, shapes, ops = bench.peps_network(8, 8, bond)
-labels, path, rep = cdist.staged_plan(einstr, shapes, min_slices=64, max_intermediate=2 ** 32 if big else None)
+cap = 2 ** int(sys.argv[3]) if len(sys.argv) > 3 else 2 ** 32          # bond 16: the plan's largest tensor (elements)
+labels, path, rep = cdist.staged_plan(einstr, shapes, min_slices=64, max_intermediate=cap if big else None)
 dev = torch.device("cuda", 0)
 warm, iters = (1, 1) if big else (4, 20)
 
