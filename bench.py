@@ -175,15 +175,18 @@ def main():
         dist.destroy_process_group()
 
 
-def batched_secondary(args, result, world, rank, backend, dev, batch=None, out=None):
+def batched_secondary(args, result, world, rank, backend, dev, batch=None, out=None, replicas=1):
     """BASELINE config 3b next to the headline: `--batch` inputs per GPU through ONE 100-site MPS (D = 256, d = 4)
     hanging on a batch hyperedge - the reference paper's ML workload (README Fig. 1d).  Data-parallel over the
     batch (weak scaling, no collective on the data path: SURVEY.md 8e); value = inputs/s over all ranks.  On one
     GPU the first 64 outputs are checked against the oracle run on those 64 inputs alone (batch independence).
-    Errors are recorded in the object; the headline line is printed regardless."""
+    `replicas` > 1: that many BATCHES (own inputs, the same cores) as replicas of one launch sequence - how batches too
+    small to fill the chip by themselves are meant to be run (1024 inputs are 64 row blocks of the sweep: a quarter of
+    the CUs).  Errors are recorded in the object; the headline line is printed regardless."""
     import torch
     import torch.distributed as dist
 
+    RB = int(replicas)
     if out is None:
         out = result.setdefault("batched_mps", {}) if rank == 0 else {}
     try:
@@ -208,12 +211,15 @@ def batched_secondary(args, result, world, rank, backend, dev, batch=None, out=N
             tn.connect_nodes(hub, inp, i, 0)
         shapes = [c.shape for c in cores] + [(B, phys)] * n_sites
         path = ssa_to_linear(nets.batched_mps_path(n_sites), 2 * n_sites)
-        bc = BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=1, device=dev.index)
+        bc = BatchedContraction(tn.einsum_str, shapes, np.float32, optimize=path, replicas=RB, device=dev.index)
         gen = torch.Generator(device=dev)
         gen.manual_seed(11 + rank)
         ops = [torch.randn(sh, generator=gen, device=dev) / 4.0 for sh in shapes]
-        res = torch.zeros((1,) + tuple(bc.plan.out_shape), device=dev)
-        launch = bc.executor.make_enqueue([t.data_ptr() for t in ops], [res[0].data_ptr()])
+        # further batches: their own inputs, the cores of the first
+        more = [[torch.randn(sh, generator=gen, device=dev) / 4.0 for sh in shapes[n_sites:]] for _ in range(RB - 1)]
+        sets = [ops] + [ops[:n_sites] + m_ for m_ in more]
+        res = torch.zeros((RB,) + tuple(bc.plan.out_shape), device=dev)
+        launch = bc.executor.make_enqueue([t.data_ptr() for set_ in sets for t in set_], [res[r_].data_ptr() for r_ in range(RB)])
         for _ in range(3):
             launch()
         bc.executor.synchronize()
@@ -235,10 +241,11 @@ def batched_secondary(args, result, world, rank, backend, dev, batch=None, out=N
         infos = bc.plan.step_infos()
         launches = sum(i["kernel"] != 5 for i in infos)
         out.update({
-            "workload": f"batched_mps_{n_sites}sites_D{bond}_d{phys}_B{B}_per_gpu", "value": round(world * B / sec, 1),
+            "workload": f"batched_mps_{n_sites}sites_D{bond}_d{phys}_B{B}_per_gpu" + (f"_x{RB}_batches_in_flight" if RB > 1 else ""),
+            "value": round(world * RB * B / sec, 1),
             "unit": "inputs/s", "ms_per_pass": round(sec * 1e3, 4), "passes": K, "scaling": "weak",
-            "achieved_tflops": round(world * bc.plan.flops / sec / 1e12, 2),
-            "frac_of_mfma_peak": round(bc.plan.flops / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "achieved_tflops": round(world * RB * bc.plan.flops / sec / 1e12, 2),
+            "frac_of_mfma_peak": round(RB * bc.plan.flops / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "launches_per_pass": launches, "epilogue_summed_steps": sum(i["epilogue_sum"] > 0 for i in infos),
             "largest_intermediate_elements": max(i["out_numel"] for i in infos if i["kernel"] != 5),
         })
@@ -258,7 +265,7 @@ def batched_secondary(args, result, world, rank, backend, dev, batch=None, out=N
             # also bracket the three bookkeeping launches behind it (k_sweep_logs, k_sweep_z, k_sweep_finish)
             members = [i for i in dom if i == sweep[0] or (i < sweep[0] and tiles[i] == (1, 1))]
             us = float(ms[sweep[0]]) * 1e3
-            fl = float(sum(infos[i]["flops"] for i in members))
+            fl = float(sum(infos[i]["flops"] for i in members)) * RB
             out["launches_per_pass"] = sum(i["kernel"] != 5 for k, i in enumerate(infos) if tiles[k] != (1, 1)) + 3
             out["sites_in_one_launch"] = len(members)
             out["dominant_kernel"] = {
@@ -271,7 +278,7 @@ def batched_secondary(args, result, world, rank, backend, dev, batch=None, out=N
             }
         elif dom:
             us = float(np.mean(ms[dom])) * 1e3
-            fl = float(np.mean([infos[i]["flops"] for i in dom]))
+            fl = float(np.mean([infos[i]["flops"] for i in dom])) * RB
             out["dominant_kernel"] = {
                 "kernel": "k_mfma_f32<..., EPW> (one launch per site: GEMM + re-weighted sum over the physical leg in the epilogue)",
                 "bound": "mfma", "launches_per_pass": len(dom), "avg_launch_us": round(us, 2), "flop_per_launch": fl,
@@ -283,13 +290,16 @@ def batched_secondary(args, result, world, rank, backend, dev, batch=None, out=N
             from oracle import cpu_ref
 
             _dev_log, resc = bc.executor.fetch()
-            c = float(accumulate_log_scale(resc[0], np.dtype(np.float32)))
-            got = res[0, :64].cpu().numpy().astype(np.float64) * np.exp(c)
-            h_ops = [o[:64].cpu().numpy() if tuple(o.shape) == (B, phys) else o.cpu().numpy() for o in ops]
-            rt, rc = cpu_ref.contract(tn.einsum_str, *h_ops, path=list(path), split_format=True)
-            ref = np.asarray(rt, dtype=np.float64) * np.exp(float(rc))
-            err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
-            out["parity_vs_oracle_first_64_inputs"] = {"ok": bool(err <= 1e-3), "max_rel_err": err, "tolerance": 1e-3}
+            err = 0.0
+            for r_ in sorted({0, RB - 1}):          # the first and the last batch in flight
+                c = float(accumulate_log_scale(resc[r_], np.dtype(np.float32)))
+                got = res[r_, :64].cpu().numpy().astype(np.float64) * np.exp(c)
+                h_ops = [o[:64].cpu().numpy() if tuple(o.shape) == (B, phys) else o.cpu().numpy() for o in sets[r_]]
+                rt, rc = cpu_ref.contract(tn.einsum_str, *h_ops, path=list(path), split_format=True)
+                ref = np.asarray(rt, dtype=np.float64) * np.exp(float(rc))
+                err = max(err, float(np.max(np.abs(got - ref)) / np.max(np.abs(ref))))
+            out["parity_vs_oracle_first_64_inputs"] = {"ok": bool(err <= 1e-3), "max_rel_err": err, "tolerance": 1e-3,
+                                                       "batches_checked": sorted({0, RB - 1})}
     except Exception as exc:  # noqa: BLE001 - recorded, the headline line must still be printed
         if rank == 0:
             out["error"] = repr(exc)
@@ -443,6 +453,9 @@ def configs_secondary(args, result, world, rank, backend, dev):
     b1024 = {}
     batched_secondary(args, result, world, rank, backend, dev, batch=1024, out=b1024)
     cfgs["cfg3b_B1024"] = b1024
+    b1024x4 = {}      # ... and what small batches are meant to do: several in flight as replicas of one launch sequence
+    batched_secondary(args, result, world, rank, backend, dev, batch=1024, out=b1024x4, replicas=4)
+    cfgs["cfg3b_B1024_x4_in_flight"] = b1024x4
     n = 1024
     leg("cfg4_i_cp_hyper", lambda: cfg4("ac,ad,ae->cde", [(n, n)] * 3, 5, 32.0, spot_cp))
     leg("cfg4_ii_tucker_dense_hub", lambda: cfg4("abc,ae,bf,cg->efg", [(n, n, n)] + [(n, n)] * 3, 7, 32.0, spot_tucker))

@@ -50,6 +50,8 @@ def test_bench_line_contract(dtype):
         assert cfgs["cfg1"]["known_answer"]["ok"] is True and cfgs["cfg1"]["device_us_per_contraction"] > 0
         assert cfgs["cfg2"]["known_answer"]["ok"] is True and cfgs["cfg2"]["known_answer"]["log_scale_hex"] == "0x1.12a72fbccf574p+10"
         assert cfgs["cfg3b_B1024"]["workload"].endswith("B1024_per_gpu") and cfgs["cfg3b_B1024"]["value"] > 0
+        x4 = cfgs["cfg3b_B1024_x4_in_flight"]         # four batches of 1024 as replicas of one launch sequence
+        assert "error" not in x4 and x4["workload"].endswith("x4_batches_in_flight") and x4["value"] > 0, x4
         for name in ("cfg4_i_cp_hyper", "cfg4_ii_tucker_dense_hub", "cfg4_iii_tucker_delta_hub", "cfg4_iv_cp_wide_r4096"):
             assert cfgs[name]["spot_check_vs_definition_f64"]["ok"] is True and 0 < cfgs[name]["frac_of_mfma_peak"] < 1
         # the hyperedge route and the materialised delta hub give the same entry (same factor matrices)
