@@ -507,9 +507,11 @@ def peps_secondary(args, result, world, rank, local_rank, backend, dev):
                         "strong_scaling", "cross_check")
                 short = {k: full[k] for k in keep if k in full}
                 if "config" in full:
-                    short["config"] = {k: full["config"][k] for k in ("workload", "slices", "slices_per_gpu",
-                                                                      "work_overhead_vs_unsliced",
-                                                                      "flop_per_contraction_sliced")}
+                    short["config"] = {k: full["config"].get(k) for k in ("workload", "slices", "slices_per_gpu",
+                                                                          "work_overhead_vs_unsliced",
+                                                                          "flop_per_contraction_sliced",
+                                                                          "largest_intermediate_elements",
+                                                                          "hbm_free_gib_with_all_stage_buffers_allocated")}
                     r = full["roofline"]
                     short["dominant_kernel"] = {k: r[k] for k in ("kernel", "bound", "achieved", "unit", "frac",
                                                                   "share_of_device_time")}
