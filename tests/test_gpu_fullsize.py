@@ -407,3 +407,40 @@ def test_absorption_chain_on_boundary_tensors_of_2_to_the_32_elements():
     del Bt, out
     torch.cuda.empty_cache()
     E.clear_caches()
+
+
+def test_absorption_chain_in_float64_on_a_2_to_the_31_element_boundary_tensor():
+    """The same chain in fp64 (16 GiB operand, 16 GiB results): the planner's rule for results of 2^31 elements is not an
+    fp32 rule - 256 rows stay 256 rows, the outermost kept column leg becomes a batch label - and the fp64 large-tile
+    kernel runs the steps; against torch in float64 slab by slab."""
+    import torch
+
+    from contractn_amd.einsum import BatchedContraction
+
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(35)
+    n, nx = 256, 128
+    Bt = torch.randn((nx, n, n, n), generator=gen, device="cuda", dtype=torch.float64) * 0.0625      # [x][k][y][z]
+    A1 = torch.randn((n, n), generator=gen, device="cuda", dtype=torch.float64) * 0.0625
+    A2 = torch.randn((n, n), generator=gen, device="cuda", dtype=torch.float64) * 0.0625
+    wz = torch.randn((n,), generator=gen, device="cuda", dtype=torch.float64)
+    wx = torch.randn((nx,), generator=gen, device="cuda", dtype=torch.float64)
+    einstr, path = "km,xkyz,yp,z,x->mp", ((0, 1), (0, 3), (0, 2), (0, 1))
+    shapes = [tuple(t.shape) for t in (A1, Bt, A2, wz, wx)]
+    bc = BatchedContraction(einstr, shapes, np.float64, optimize=path, replicas=1)
+    infos = bc.plan.step_infos()
+    assert infos[0]["out_numel"] == 2 ** 31 and infos[0]["m"] == 256 and infos[0]["k"] == 256 and infos[0]["batch"] >= 2, infos[0]
+    assert infos[1]["out_numel"] == 2 ** 31 and infos[1]["m"] == 256 and infos[1]["k"] == 256, infos[1]
+    out = torch.zeros((n, n), device="cuda", dtype=torch.float64)
+    launch = bc.executor.make_enqueue([t.data_ptr() for t in (A1, Bt, A2, wz, wx)], [out.data_ptr()])
+    launch()
+    logs = bc.fetch_log_scale()
+    got = out * float(np.exp(logs[0]))
+    ref = torch.zeros((n, n), device="cuda", dtype=torch.float64)
+    for x in range(nx):
+        ref += wx[x] * (A1.T @ (Bt[x] @ wz) @ A2)
+    assert float((got - ref).abs().max() / ref.abs().max()) <= 1e-10
+    bc.executor.close()
+    del Bt, out
+    torch.cuda.empty_cache()
+    E.clear_caches()
