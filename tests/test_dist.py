@@ -441,3 +441,40 @@ def test_hoisted_cost_counts_evaluations_per_dependency_set():
     # b lives in the left half only: the right half (cd,de) is evaluated once, the rest 8 times at 1/8 of the size
     assert tot_b < one_b * 8 and tot_b == base + (8 - 1) * 4 * 16 * 4
     assert paths.hoisted_cost(sets, "ae", sizes, path, ["b"], parallel=8)[0] == one_b * 8
+
+
+def test_bond16_plan_shards_as_documented():
+    """The shipped 256-slice plan of the 8 x 8, D = 16 grid (two sliced labels, tensors of up to 2^32 elements): no work
+    beyond the unsliced tree's on one rank, and the busiest rank's modelled work at 2 / 4 / 8 ranks under the rank grid the
+    staged contraction picks (at 8 ranks the grid is 1 x 8 and 36 + 35 of a rank's 124 TFLOP are
+    stages every rank computes in full)."""
+    import bench
+    from contractn_amd import paths
+
+    einstr, shapes, _ops = bench.peps_network(8, 8, 16)
+    shapes = [tuple(int(d) for d in s) for s in shapes]
+    labels, path, rep = D.staged_plan(einstr, shapes, min_slices=64, max_intermediate=2 ** 32)
+    assert rep["slices"] == 256 and len(labels) == 2 and rep["largest_intermediate"] == 2 ** 32
+    assert abs(rep["work_overhead"] - 1.0) < 1e-3
+    _terms, _out, sizes = paths.parse_einsum_input(einstr, shapes)
+    sd = D.stage_decomposition(einstr, shapes, tuple(labels), path, min_saved=1 << 28)
+    at = {lab: i for i, lab in enumerate(labels)}
+    dep_idx = [[at[lab] for lab in st["dep"]] for st in sd]
+    extents = [sizes[lab] for lab in labels]
+    work = []
+    for st in sd:
+        lhs_ = st["einsum"].split("->")[0].split(",")
+        work.append(paths.path_cost([set(t_) for t_ in lhs_], st["out"], sizes, st["path"])[0] if len(lhs_) > 1 else 0)
+
+    def busiest(world):
+        grid = D._best_rank_grid(extents, world, dep_idx, work)
+        return grid, sum(w_ * int(np.prod([-(-extents[j] // grid[j]) for j in dep])) for dep, w_ in zip(dep_idx, work))
+
+    g1, w1 = busiest(1)
+    assert abs(w1 / rep["unsliced_flops"] - 1.0) < 1e-3
+    g8, w8 = busiest(8)
+    assert sorted(g8) == [1, 8]
+    assert 3.9 < w1 / w8 < 4.1                    # the model's ceiling for 8 ranks (measured per-rank timing: 3.5 x)
+    replicated = sum(w_ for dep, w_ in zip(dep_idx, work) if not dep) + min(
+        sum(w_ * extents[dep[0]] for dep, w_ in zip(dep_idx, work) if dep == [j]) for j in range(2))
+    assert 0.5 < replicated / w8 < 0.65           # what every rank computes in full: more than half of its work
